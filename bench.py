@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-timestep field update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One bench "step" is one reference step (runSingleStep): three forward-Euler sweeps of the six
+equations plus the live time-filter pass, over the whole grid.  Workload at N = 1: the shipped
+case scaled to a 2-D 4096 x 4096 synthetic grid (cases.synthetic_2d, seed 1).  For N > 1 the
+grid is slab-decomposed along x, one process per GPU, 4096 planes per GPU (weak scaling), with
+the halo planes exchanged before every sweep.
+
+Prints ONE JSON line (rank 0): whole-job cell-updates/s with the inputs already resident in
+HBM, the sweep kernel's roofline object (HIP-event kernel time measured in the timed region)
+and, at N = 1, the CPU baseline (the C restatement under oracle/, timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak (spec)
+BYTES_PER_UPDATE_2D = 81        # 5 fields x 8 B x (read + write) + 1 B mask
+BYTES_PER_UPDATE_3D = 97        # 6 fields x 8 B x (read + write) + 1 B mask
+SWEEPS_PER_STEP = 3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=4096, help="x-planes per GPU")
+    ap.add_argument("--ny", type=int, default=4096)
+    ap.add_argument("--nz", type=int, default=1)
+    ap.add_argument("--flags", type=int, default=0, help="cfd_params.flags (1 = one-thread-per-cell kernel)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="edge of the square CPU-baseline sample grid")
+    return ap.parse_args()
+
+
+def cpu_baseline(edge):
+    """Times the C restatement (oracle/, kind = "port") on a bounded sample of the same recipe."""
+    from cfd_amd import cases
+    from oracle import OracleB
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_params
+    cores = min(16, os.cpu_count() or 1)
+    params, fields, active = cases.synthetic_2d(edge, edge, seed=1)
+    b = OracleB(oracle_params(params), fields, active, pow_mode=1, nthreads=cores)
+    b.step(1)                                   # untimed: first touch of the table
+    t0 = time.perf_counter()
+    nsteps = 2
+    b.step(nsteps)
+    dt = time.perf_counter() - t0
+    b.close()
+    return {"value": edge * edge * SWEEPS_PER_STEP * nsteps / dt, "unit": "cell-updates/s", "cores": cores,
+            "kind": "port",
+            "sample": "synthetic_2d %dx%d (same recipe and seed as the workload), %d steps = %d sweeps + filters, "
+                      "C restatement with OpenMP, %.1f s" % (edge, edge, nsteps, SWEEPS_PER_STEP * nsteps, dt)}
+
+
+def measured_traffic(workload):
+    """HBM bytes per sweep launch from a separate rocprofv3 --pmc pass, if one was recorded."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec.get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cfd_amd import cases
+    from cfd_amd.slab import SlabGraph
+
+    two_d = a.nz == 1
+    if two_d:
+        params, fields, active = cases.synthetic_2d(a.nx, a.ny, seed=1 + rank)
+    else:
+        params, fields, active = cases.synthetic_3d(a.nx, a.ny, a.nz, seed=3 + rank)
+    params["device"] = local_rank
+    params["flags"] = a.flags
+    g = SlabGraph(params, fields, active, rank=rank, world=world)
+    del fields
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        g.sync()
+
+    for _ in range(a.warmup):
+        g.step(1)
+    barrier()
+    g.graph.set_timing(True)
+    g.graph.sweep_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        g.step(1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = g.graph.sweep_timing(reset=True)
+    g.graph.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cells_per_gpu = a.nx * a.ny * a.nz
+    updates = cells_per_gpu * world * SWEEPS_PER_STEP * a.steps
+    bytes_per_update = BYTES_PER_UPDATE_2D if g.graph.live_fields == 5 else BYTES_PER_UPDATE_3D
+    avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+    achieved = cells_per_gpu * bytes_per_update / avg_kernel_s / 1e9
+    workload = ("synthetic_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if two_d else \
+        ("synthetic_3d %dx%dx%d per GPU" % (a.nx, a.ny, a.nz))
+    out = {
+        "metric": "fp64 cell-updates/sec",
+        "value": updates / elapsed,
+        "unit": "cell-updates/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": workload, "cells_per_gpu": cells_per_gpu, "sweeps_per_step": SWEEPS_PER_STEP,
+                   "filter_passes_per_step": 1, "decomposition": "x-slabs, %d rank(s)" % world,
+                   "kernel": g.graph.kernel_name()},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(workload),
+                     "kernel": "sweep", "bytes_per_cell_update": bytes_per_update,
+                     "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches},
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
+        print(json.dumps(out), flush=True)
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

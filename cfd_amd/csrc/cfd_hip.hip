@@ -1,0 +1,514 @@
+// libcfdhip.so -- fp64 HIP kernels (gfx950) and the C ABI declared in include/cfd_hip.h.
+//
+// Device layout ("plane-interleaved structure of arrays"): one time slot is
+//     value(f, x, y, z) = slot[ ((x+1)*NF + f) * (ny*nz) + y*nz + z ]
+// i.e. for every x-plane the NF live fields lie back to back, each as ny*nz contiguous
+// doubles.  Lanes run along the fastest index (y*nz+z), so accesses coalesce exactly as in a
+// plain structure of arrays, while a whole x-plane of all fields is ONE contiguous run: the
+// slab halo that a neighbouring GPU needs is a single message with no pack kernel.  Plane -1
+// and plane nx are ghost planes (used only when a neighbouring slab exists).
+//
+// Four buffers per handle: the three time slots of the reference plus one scratch slot that
+// receives a sweep which does not advance time (the reference rebuilds slot t from a snapshot
+// of slot t; here the result lands in scratch and the two buffers trade roles).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cfd_hip.h"
+#include "sweep_math.h"
+
+using namespace cfd;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(CFD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+struct cfd_handle {
+    cfd_params p;
+    int nf;                 // live fields on the device: 5 (2-D, W == 0) or 6
+    bool two_d;
+    size_t plane;           // ny*nz
+    size_t slot_elems;      // nf * (nx+2) * plane
+    double* buf[4];         // three time slots + scratch
+    int map[4];             // map[t] = buffer holding time slot t (t = 0..2); map[3] = scratch
+    uint8_t* d_active;      // (nx+2) * plane bytes, ghost planes zero
+    double* d_partial;      // reduction partials
+    int n_partial;
+    std::vector<double> mew;   // stored Mew: set at creation, never read by the update
+    hipStream_t stream;
+    bool own_stream;
+    int device;
+    int cmt, cat;
+    SweepConsts K;
+    // sweep timing
+    bool timing;
+    std::vector<EventPair> ev_used, ev_free;
+    double t_ms;
+    int64_t t_launches;
+};
+
+// field order inside a plane
+//   2-D: U V Density Temperature Dye          (sweep_math.h F2_*)
+//   3-D: U V W Density Temperature Dye
+static const int kProp2[5] = {0, 1, 3, 4, 6};          // device field -> propIndex
+static const int kProp3[6] = {0, 1, 2, 3, 4, 6};
+
+static inline double* slot_base(const cfd_handle* h, int t) {
+    // points at plane x = 0, field 0
+    return h->buf[h->map[t]] + (size_t)h->nf * h->plane;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+// One thread per cell; every thread evaluates phase A for its cell and again for its four face
+// neighbours.  Redundant by design: this is the plain reading of the update, kept as the
+// on-device cross-check of the tiled kernel.
+__device__ __forceinline__ void load5(const double* __restrict__ src, long plane5, int ny, int x, int y,
+                                      double v[NF2]) {
+    const double* p = src + (long)x * plane5 + y;
+#pragma unroll
+    for (int f = 0; f < NF2; ++f) v[f] = p[(long)f * ny];
+}
+
+__device__ __forceinline__ void phaseA2_at(const SweepConsts& K, const double* __restrict__ src, long plane5,
+                                           int ny, int x, int y, int xlo, int xhi, PhaseA2& o) {
+    const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
+    const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
+    double c[NF2], e[NF2], w[NF2], n[NF2], s[NF2];
+    load5(src, plane5, ny, x, y, c);
+    load5(src, plane5, ny, xe, y, e);
+    load5(src, plane5, ny, xw, y, w);
+    load5(src, plane5, ny, x, yn, n);
+    load5(src, plane5, ny, x, ys, s);
+    phaseA2(K, c, e, w, n, s, o);
+}
+
+__global__ void __launch_bounds__(64)
+sweep2d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict__ dst,
+               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.y;
+    if (y >= ny || x >= nx) return;
+    const long plane5 = (long)NF2 * ny;
+    const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
+    const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
+    PhaseA2 C, T;
+    ShareX2 XE, XW;
+    ShareY2 YN, YS;
+    phaseA2_at(K, src, plane5, ny, x, y, xlo, xhi, C);
+    phaseA2_at(K, src, plane5, ny, xe, y, xlo, xhi, T);  XE = T.sx;
+    phaseA2_at(K, src, plane5, ny, xw, y, xlo, xhi, T);  XW = T.sx;
+    phaseA2_at(K, src, plane5, ny, x, yn, xlo, xhi, T);  YN = T.sy;
+    phaseA2_at(K, src, plane5, ny, x, ys, xlo, xhi, T);  YS = T.sy;
+    double o[5];
+    phaseB2(K, C, XE, XW, YN, YS, o);
+    const bool act = active[(long)x * ny + y] != 0;
+    const double* sp = src + (long)x * plane5 + y;
+    double* dp = dst + (long)x * plane5 + y;
+    dp[(long)F2_RHO * ny] = o[E2_RHO];
+    dp[(long)F2_T * ny] = o[E2_T];
+    dp[(long)F2_U * ny] = act ? o[E2_U] : sp[(long)F2_U * ny];
+    dp[(long)F2_V * ny] = act ? o[E2_V] : sp[(long)F2_V * ny];
+    dp[(long)F2_DYE * ny] = act ? o[E2_DYE] : sp[(long)F2_DYE * ny];
+}
+
+// correctPrevTime: prev <- pp + 0.5*(c - pp); Density and Temperature in every cell, the
+// other fields only where the cell is active.  Grid: (ceil(plane/256), nf, nx).
+__global__ void __launch_bounds__(256)
+time_filter_kernel(const double* __restrict__ cur, const double* __restrict__ pp, double* __restrict__ prev,
+                   const uint8_t* __restrict__ active, long plane, int nf, unsigned always_mask) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const int f = blockIdx.y;
+    const long x = blockIdx.z;
+    const long o = (x * nf + f) * plane + i;
+    const bool always = (always_mask >> f) & 1u;
+    if (always || active[x * plane + i]) {
+        const double c = cur[o], p = pp[o];
+        prev[o] = p + (0.5 * (c - p));
+    }
+}
+
+// Sum of one field over the owned planes.  Stage 1: fixed grid, grid-stride, wavefront shuffle,
+// then LDS across the block's waves; one partial per block.  Stage 2: one block folds the
+// partials.  Fixed launch geometry makes the result reproducible from run to run.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+sum_field_stage1(const double* __restrict__ base, long plane, int nf, int f, int nx, double* __restrict__ partial) {
+    __shared__ double wsum[4];
+    const long total = (long)nx * plane;
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long x = i / plane, r = i - x * plane;
+        acc += base[(x * nf + f) * plane + r];
+    }
+    acc = wave_sum(acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) wsum[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+__global__ void __launch_bounds__(256)
+sum_field_stage2(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double wsum[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
+    acc = wave_sum(acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) wsum[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
+    const cfd_params& p = h->p;
+    const int xlo = p.ghost_lo ? -1 : 0;
+    const int xhi = p.ghost_hi ? p.nx : p.nx - 1;
+    EventPair ev{};
+    if (h->timing) {
+        if (h->ev_free.empty()) {
+            HIP_TRY(hipEventCreate(&ev.a));
+            HIP_TRY(hipEventCreate(&ev.b));
+        } else {
+            ev = h->ev_free.back();
+            h->ev_free.pop_back();
+        }
+        HIP_TRY(hipEventRecord(ev.a, h->stream));
+    }
+    if (h->two_d) {
+        dim3 block(64), grid((p.ny + 63) / 64, p.nx);
+        hipLaunchKernelGGL(sweep2d_simple, grid, block, 0, h->stream, h->K, src, dst,
+                           h->d_active + h->plane, p.nx, p.ny, xlo, xhi);
+    } else {
+        return fail(CFD_E_STATE, "3-D sweep kernel not built into this library yet");
+    }
+    HIP_TRY(hipGetLastError());
+    if (h->timing) {
+        HIP_TRY(hipEventRecord(ev.b, h->stream));
+        h->ev_used.push_back(ev);
+    }
+    return CFD_OK;
+}
+
+extern "C" {
+
+const char* cfd_last_error(void) { return g_err.c_str(); }
+
+int cfd_default_params(cfd_params* p) {
+    if (!p) return fail(CFD_E_ARG, "cfd_default_params: null pointer");
+    std::memset(p, 0, sizeof *p);
+    p->nx = 301; p->ny = 151; p->nz = 1;
+    p->dx = 1.6 / 301.0; p->dy = 0.8 / 151.0; p->dz = 1.0 / 1.0;
+    p->dt = 0.00001;
+    p->suth = 120.0;
+    {
+        // sutherlandLambda = initialMew*(initialTemperature + S)/(initialTemperature**1.5)
+        const double t0 = 223.0;
+        p->lambda = (0.1 * (t0 + 120.0)) / pow(t0, 1.5);
+    }
+    p->cv = 716.0;
+    p->R = 1005.0 - 716.0;
+    p->k = 0.025;
+    p->dye_f = 0.001;
+    p->device = -1;
+    p->flags = CFD_FLAG_DEFAULT;
+    p->ghost_lo = p->ghost_hi = 0;
+    return CFD_OK;
+}
+
+void cfd_destroy(cfd_handle* h) {
+    if (!h) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& e : h->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (int i = 0; i < 4; ++i)
+        if (h->buf[i]) (void)hipFree(h->buf[i]);
+    if (h->d_active) (void)hipFree(h->d_active);
+    if (h->d_partial) (void)hipFree(h->d_partial);
+    if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete h;
+}
+
+int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
+               cfd_handle** out) {
+    if (!p || !fields || !active || !out) return fail(CFD_E_ARG, "cfd_create: null pointer");
+    *out = nullptr;
+    if (p->nx < 1 || p->ny < 1 || p->nz < 1) return fail(CFD_E_ARG, "cfd_create: grid extents must be >= 1");
+    if (!(p->dx > 0) || !(p->dy > 0) || !(p->dz > 0) || !(p->dt > 0))
+        return fail(CFD_E_ARG, "cfd_create: dx, dy, dz, dt must be > 0");
+    for (int i = 0; i < CFD_NPROP; ++i)
+        if (!fields[i]) return fail(CFD_E_ARG, "cfd_create: null field pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(CFD_E_DEVICE, "cfd_create: no HIP device available (this library has no CPU path)");
+    int dev = p->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(CFD_E_ARG, "cfd_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(dev));
+
+    cfd_handle* h = new cfd_handle();
+    h->p = *p;
+    h->device = dev;
+    h->plane = (size_t)p->ny * p->nz;
+    const size_t n = (size_t)p->nx * h->plane;
+    // 2-D specialisation applies when nz == 1 and W is +0 in every owned cell.
+    bool w_zero = true;
+    {
+        const uint64_t* wb = reinterpret_cast<const uint64_t*>(fields[2]);
+        for (size_t i = 0; i < n; ++i)
+            if (wb[i] != 0) { w_zero = false; break; }
+    }
+    h->two_d = (p->nz == 1) && w_zero && !(p->flags & CFD_FLAG_FORCE_3D);
+    h->nf = h->two_d ? 5 : 6;
+    h->slot_elems = (size_t)h->nf * (p->nx + 2) * h->plane;
+    h->K = make_consts(p->dx, p->dy, p->dz, p->dt, p->lambda, p->suth, p->R, p->cv, p->k, p->dye_f);
+    h->cmt = 0; h->cat = 0;
+    for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
+    h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;
+    h->timing = false; h->t_ms = 0.0; h->t_launches = 0;
+    h->mew.assign(fields[5], fields[5] + n);
+
+#define CREATE_TRY(expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            std::string m = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+            cfd_destroy(h);                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? CFD_E_MEMORY : CFD_E_DEVICE, m);           \
+        }                                                                                      \
+    } while (0)
+
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) {
+        CREATE_TRY(hipMalloc((void**)&h->buf[i], h->slot_elems * sizeof(double)));
+        CREATE_TRY(hipMemsetAsync(h->buf[i], 0, h->slot_elems * sizeof(double), h->stream));
+    }
+    CREATE_TRY(hipMalloc((void**)&h->d_active, (size_t)(p->nx + 2) * h->plane));
+    CREATE_TRY(hipMemsetAsync(h->d_active, 0, (size_t)(p->nx + 2) * h->plane, h->stream));
+    h->n_partial = 1024;
+    CREATE_TRY(hipMalloc((void**)&h->d_partial, (h->n_partial + 1) * sizeof(double)));
+    CREATE_TRY(hipMemcpyAsync(h->d_active + h->plane, active, n, hipMemcpyHostToDevice, h->stream));
+    // slot 0 from the host fields, plane-interleaved; then slots 1, 2 and scratch as device copies
+    const int* prop = h->two_d ? kProp2 : kProp3;
+    const size_t row = h->plane * sizeof(double);
+    for (int f = 0; f < h->nf; ++f) {
+        double* d = h->buf[0] + ((size_t)h->nf + f) * h->plane;
+        CREATE_TRY(hipMemcpy2DAsync(d, (size_t)h->nf * row, fields[prop[f]], row, row, p->nx,
+                                    hipMemcpyHostToDevice, h->stream));
+    }
+    for (int i = 1; i < 4; ++i)
+        CREATE_TRY(hipMemcpyAsync(h->buf[i], h->buf[0], h->slot_elems * sizeof(double), hipMemcpyDeviceToDevice,
+                                  h->stream));
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    *out = h;
+    return CFD_OK;
+}
+
+int cfd_sweep(cfd_handle* h, int step_time) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sweep: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const double* src = slot_base(h, h->cmt);
+    if (step_time) {
+        const int nc = (h->cmt + 1) % 3;
+        int rc = launch_sweep(h, src, slot_base(h, nc));
+        if (rc) return rc;
+        h->cmt = nc;
+        h->cat += 1;
+    } else {
+        int rc = launch_sweep(h, src, slot_base(h, 3));
+        if (rc) return rc;
+        const int t = h->map[h->cmt];
+        h->map[h->cmt] = h->map[3];
+        h->map[3] = t;
+    }
+    return CFD_OK;
+}
+
+int cfd_time_filter(cfd_handle* h) {
+    if (!h) return fail(CFD_E_ARG, "cfd_time_filter: null handle");
+    if (!(h->cat > 1)) return CFD_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int tb = (h->cmt + 2) % 3, tc = (tb + 2) % 3;
+    // Density and Temperature are always filtered; U, V, W, Dye only in active cells
+    const unsigned always = h->two_d ? ((1u << F2_RHO) | (1u << F2_T)) : ((1u << 3) | (1u << 4));
+    dim3 block(256), grid((unsigned)((h->plane + 255) / 256), h->nf, h->p.nx);
+    hipLaunchKernelGGL(time_filter_kernel, grid, block, 0, h->stream, slot_base(h, h->cmt), slot_base(h, tc),
+                       slot_base(h, tb), h->d_active + h->plane, (long)h->plane, h->nf, always);
+    HIP_TRY(hipGetLastError());
+    return CFD_OK;
+}
+
+int cfd_step(cfd_handle* h, int nsteps) {
+    if (!h) return fail(CFD_E_ARG, "cfd_step: null handle");
+    if (nsteps < 0) return fail(CFD_E_ARG, "cfd_step: nsteps must be >= 0");
+    for (int i = 0; i < nsteps; ++i) {
+        // The filter after the first and second sweep of a step writes values that the filter
+        // after the third overwrites from the same inputs (slot t-2 and the mask do not change,
+        // slot t-1 is not read by any sweep), so only the last of the three is launched.
+        int rc;
+        if ((rc = cfd_sweep(h, 1))) return rc;
+        if ((rc = cfd_sweep(h, 0))) return rc;
+        if ((rc = cfd_sweep(h, 0))) return rc;
+        if ((rc = cfd_time_filter(h))) return rc;
+    }
+    return CFD_OK;
+}
+
+int cfd_total_density(cfd_handle* h, double* out) {
+    if (!h || !out) return fail(CFD_E_ARG, "cfd_total_density: null pointer");
+    HIP_TRY(hipSetDevice(h->device));
+    const int t = (h->cmt + 2) % 3;
+    const int f = h->two_d ? F2_RHO : 3;
+    const long total = (long)h->p.nx * (long)h->plane;
+    int nb = (int)((total + 255) / 256);
+    if (nb > h->n_partial) nb = h->n_partial;
+    hipLaunchKernelGGL(sum_field_stage1, dim3(nb), dim3(256), 0, h->stream, slot_base(h, t), (long)h->plane, h->nf,
+                       f, h->p.nx, h->d_partial);
+    hipLaunchKernelGGL(sum_field_stage2, dim3(1), dim3(256), 0, h->stream, h->d_partial, nb,
+                       h->d_partial + h->n_partial);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->d_partial + h->n_partial, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CFD_OK;
+}
+
+int cfd_read_fields(cfd_handle* h, int slot_rel, double* const out[CFD_NPROP]) {
+    if (!h || !out) return fail(CFD_E_ARG, "cfd_read_fields: null pointer");
+    if (slot_rel < 0 || slot_rel > 2) return fail(CFD_E_ARG, "cfd_read_fields: slot_rel must be 0, 1 or 2");
+    for (int i = 0; i < CFD_NPROP; ++i)
+        if (!out[i]) return fail(CFD_E_ARG, "cfd_read_fields: null output pointer");
+    HIP_TRY(hipSetDevice(h->device));
+    const int t = ((h->cmt - slot_rel) % 3 + 3) % 3;
+    const int* prop = h->two_d ? kProp2 : kProp3;
+    const size_t row = h->plane * sizeof(double);
+    const size_t n = (size_t)h->p.nx * h->plane;
+    for (int f = 0; f < h->nf; ++f) {
+        const double* s = slot_base(h, t) + (size_t)f * h->plane;
+        HIP_TRY(hipMemcpy2DAsync(out[prop[f]], row, s, (size_t)h->nf * row, row, h->p.nx, hipMemcpyDeviceToHost,
+                                 h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->two_d) std::memset(out[2], 0, n * sizeof(double));   // W is exactly +0 throughout
+    std::memcpy(out[5], h->mew.data(), n * sizeof(double));
+    return CFD_OK;
+}
+
+int cfd_time(cfd_handle* h, int* cmt, int* cat) {
+    if (!h || !cmt || !cat) return fail(CFD_E_ARG, "cfd_time: null pointer");
+    *cmt = h->cmt;
+    *cat = h->cat;
+    return CFD_OK;
+}
+
+int cfd_halo_planes(cfd_handle* h, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
+                    size_t* plane_bytes) {
+    if (!h) return fail(CFD_E_ARG, "cfd_halo_planes: null handle");
+    double* base = slot_base(h, h->cmt);
+    const size_t pe = (size_t)h->nf * h->plane;
+    if (send_lo) *send_lo = base;
+    if (send_hi) *send_hi = base + (size_t)(h->p.nx - 1) * pe;
+    if (recv_lo) *recv_lo = h->p.ghost_lo ? (void*)(base - pe) : nullptr;
+    if (recv_hi) *recv_hi = h->p.ghost_hi ? (void*)(base + (size_t)h->p.nx * pe) : nullptr;
+    if (plane_bytes) *plane_bytes = pe * sizeof(double);
+    return CFD_OK;
+}
+
+int cfd_stream(cfd_handle* h, void** stream) {
+    if (!h || !stream) return fail(CFD_E_ARG, "cfd_stream: null pointer");
+    *stream = (void*)h->stream;
+    return CFD_OK;
+}
+
+int cfd_set_stream(cfd_handle* h, void* stream) {
+    if (!h) return fail(CFD_E_ARG, "cfd_set_stream: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream) HIP_TRY(hipStreamDestroy(h->stream));
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+    return CFD_OK;
+}
+
+const char* cfd_kernel_name(cfd_handle* h) {
+    if (!h) return "";
+    return h->two_d ? "sweep2d_simple" : "sweep3d";
+}
+
+int cfd_sync(cfd_handle* h) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sync: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return CFD_OK;
+}
+
+int cfd_set_timing(cfd_handle* h, int enable) {
+    if (!h) return fail(CFD_E_ARG, "cfd_set_timing: null handle");
+    h->timing = enable != 0;
+    return CFD_OK;
+}
+
+int cfd_sweep_timing(cfd_handle* h, double* total_ms, int64_t* launches, int reset) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sweep_timing: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto& e : h->ev_used) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+        h->t_ms += ms;
+        h->t_launches += 1;
+        h->ev_free.push_back(e);
+    }
+    h->ev_used.clear();
+    if (total_ms) *total_ms = h->t_ms;
+    if (launches) *launches = h->t_launches;
+    if (reset) { h->t_ms = 0.0; h->t_launches = 0; }
+    return CFD_OK;
+}
+
+int cfd_live_fields(cfd_handle* h, int* nfields) {
+    if (!h || !nfields) return fail(CFD_E_ARG, "cfd_live_fields: null pointer");
+    *nfields = h->nf;
+    return CFD_OK;
+}
+
+}  // extern "C"

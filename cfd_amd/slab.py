@@ -1,0 +1,172 @@
+"""Slab decomposition along x: one AdjGraph per GPU, one process per GPU.
+
+x is the slowest index of the reference's node order, so a rank's slab is a contiguous range
+of x-planes and the halo it owes each neighbour is its first / last owned plane.  The device
+layout keeps all live fields of a plane contiguous, so that halo is ONE message per neighbour
+per sweep, sent straight from / received straight into the time slot (no pack kernel).
+
+Per sweep:  exchange ghost planes of the current slot  ->  sweep.
+Per step:   3 x (exchange, sweep), one live filter pass (needs no halo).
+Reduction:  local tree sum of Density, then one all-reduce of a single double.
+
+Domain ends keep the reference's clamp-to-self rule (no wrap-around): rank 0 has no low
+ghost, the last rank no high ghost.
+
+The transport is pluggable so that the orchestration can be exercised without GPUs:
+  DistComm   torch.distributed point-to-point (backend "nccl" = RCCL over xGMI on the GPU box,
+             "gloo" in the CPU tests)
+  LocalComm  several slabs inside one process (virtual ranks), planes copied directly
+"""
+import numpy as np
+
+from .solver import AdjGraph
+
+
+class _DeviceSpan:
+    """Exposes a raw device address range to torch through the CUDA array interface."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class GpuBackend:
+    """AdjGraph on this process's GPU; halo planes are handed out as torch tensors that alias the
+    library's device memory."""
+
+    def __init__(self, params, fields, active):
+        import torch
+        self._torch = torch
+        self.graph = AdjGraph(params, fields, active)
+        # run on torch's current stream so that torch.distributed's stream ordering covers the kernels
+        self.graph.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._cache = {}
+
+    def halo_tensors(self):
+        ptrs, nbytes = self.graph.halo_planes()
+        out = []
+        for p in ptrs:
+            if not p:
+                out.append(None)
+                continue
+            t = self._cache.get(p)
+            if t is None:
+                t = self._torch.as_tensor(_DeviceSpan(p, nbytes), device="cuda")
+                self._cache[p] = t
+            out.append(t)
+        return out
+
+    def scalar_tensor(self, v):
+        return self._torch.tensor([v], dtype=self._torch.float64, device="cuda")
+
+    def __getattr__(self, name):
+        return getattr(self.graph, name)
+
+
+class DistComm:
+    """Neighbour exchange and the scalar all-reduce over torch.distributed."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def exchange(self, backend):
+        if self.world == 1:
+            return
+        dist = self.dist
+        send_lo, send_hi, recv_lo, recv_hi = backend.halo_tensors()
+        ops = []
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.isend, send_lo, self.rank - 1))
+            ops.append(dist.P2POp(dist.irecv, recv_lo, self.rank - 1))
+        if self.rank < self.world - 1:
+            ops.append(dist.P2POp(dist.isend, send_hi, self.rank + 1))
+            ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def all_sum(self, backend, v):
+        if self.world == 1:
+            return v
+        t = backend.scalar_tensor(v)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+
+class LocalComm:
+    """Virtual ranks: all slabs live in this process; `peers` is the list of SlabGraphs in rank
+    order.  Exchange copies planes directly; used to test ghost-plane handling on one device."""
+
+    def __init__(self, rank, peers):
+        self.rank, self.peers = rank, peers
+        self.world = None
+
+    def exchange(self, backend):
+        # pull model: every rank copies what it needs from its neighbours' send planes
+        me = self.rank
+        _, _, recv_lo, recv_hi = backend.halo_tensors()
+        if me > 0:
+            recv_lo.copy_(self.peers[me - 1].backend.halo_tensors()[1])
+        if me < len(self.peers) - 1:
+            recv_hi.copy_(self.peers[me + 1].backend.halo_tensors()[0])
+
+    def all_sum(self, backend, v):
+        raise NotImplementedError("sum over virtual ranks is done by the caller")
+
+
+class SlabGraph:
+    """One rank's slab.  `fields` / `active` hold this rank's owned planes only."""
+
+    def __init__(self, params, fields, active, rank=0, world=1, comm=None, backend_cls=GpuBackend):
+        p = dict(params)
+        p["ghost_lo"] = 1 if rank > 0 else 0
+        p["ghost_hi"] = 1 if rank < world - 1 else 0
+        self.rank, self.world = rank, world
+        self.backend = backend_cls(p, fields, active)
+        self.graph = self.backend.graph if hasattr(self.backend, "graph") else self.backend
+        self.comm = comm if comm is not None else DistComm(rank, world)
+
+    # the reference's verbs, slab-aware
+    def exchange(self):
+        self.comm.exchange(self.backend)
+
+    def sweep(self, step_time):
+        self.exchange()
+        self.backend.sweep(step_time)
+        return self
+
+    def time_filter(self):
+        self.backend.time_filter()
+        return self
+
+    def step(self, nsteps=1):
+        for _ in range(nsteps):
+            self.sweep(True)
+            self.sweep(False)
+            self.sweep(False)
+            self.time_filter()
+        return self
+
+    def total_density(self):
+        return self.comm.all_sum(self.backend, self.backend.total_density())
+
+    def read_fields(self, slot_rel=0):
+        return self.backend.read_fields(slot_rel)
+
+    def sync(self):
+        self.backend.sync()
+
+    def close(self):
+        self.backend.close()
+
+
+def split_slabs(fields, active, nx, plane, world):
+    """Cuts global arrays (node order, x slowest) into `world` slabs of consecutive planes.
+    Returns a list of (x_begin, x_end, fields, active)."""
+    bounds = [nx * r // world for r in range(world + 1)]
+    out = []
+    for r in range(world):
+        a, b = bounds[r] * plane, bounds[r + 1] * plane
+        out.append((bounds[r], bounds[r + 1], [np.ascontiguousarray(f[a:b]) for f in fields],
+                    np.ascontiguousarray(active[a:b])))
+    return out

@@ -1,0 +1,170 @@
+/*
+ * cfd_hip.h -- C ABI of libcfdhip.so: the per-timestep field update of the finite-volume
+ * solver (six-equation forward-Euler sweep, three-slot time filter, density reduction) as
+ * fp64 HIP kernels for gfx950.
+ *
+ * The reference program has no FFI layer; these entry points are the seam a host binds in
+ * place of its own functions.  Each declaration cites the reference function it replaces
+ * (paths are relative to the reference tree).
+ *
+ * Conventions
+ *   - Plain C types only.  The caller owns every pointer it passes; the library copies in
+ *     cfd_create and copies out in cfd_read_fields.  The handle owns all device memory.
+ *   - Return value 0 = success, negative = error (CFD_E_*); cfd_last_error() returns a
+ *     thread-local message for the most recent failure.  Nothing throws or aborts across
+ *     the boundary.
+ *   - One handle is driven from one host thread at a time (the reference is single-threaded,
+ *     CFD.cabal:11 has no -threaded).
+ *   - Field order everywhere is the reference's propIndex order
+ *     (src/SolutionDomain.hs:77-85): U, V, W, Density, Temperature, Mew, Dye.
+ *   - Node order is the reference's: index = (x*ny + y)*nz + z, x slowest
+ *     (makePositions, src/SolutionDomain.hs:388-392).
+ */
+#ifndef CFD_HIP_H
+#define CFD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFD_NPROP 7
+
+enum {
+    CFD_OK = 0,
+    CFD_E_ARG = -1,      /* bad argument (null pointer, non-positive size, bad slot) */
+    CFD_E_DEVICE = -2,   /* HIP runtime error, or no usable GPU */
+    CFD_E_MEMORY = -3,   /* allocation failed */
+    CFD_E_STATE = -4     /* call not valid in the handle's current state */
+};
+
+/* flags for cfd_params.flags */
+enum {
+    CFD_FLAG_DEFAULT = 0,
+    /* Run the one-thread-per-cell sweep kernel instead of the tiled one.  Same arithmetic;
+     * kept so that the tiled kernel can be checked against it at sizes a CPU cannot reach. */
+    CFD_FLAG_SIMPLE_KERNEL = 1,
+    /* Use the general 3-D kernel even when nz == 1 and W is identically zero. */
+    CFD_FLAG_FORCE_3D = 2,
+    /* Re-associated arithmetic: folds the geometric constants and replaces divisions by
+     * constant intervals with reciprocal multiplies.  Not bit-identical to the strict
+     * operation order; agrees with it to <= 1e-13 relative per sweep. */
+    CFD_FLAG_FAST_MATH = 4
+};
+
+/*
+ * Everything the reference hard-codes as top-level constants:
+ *   nx,ny,nz   maxPos+1                   src/SolutionDomain.hs:136-141
+ *   dx,dy,dz   cellLength                 src/SolutionDomain.hs:150-151
+ *   dt         timeStep                   src/SolutionDomain.hs:237-238
+ *   lambda     sutherlandLambda           src/SolutionDomain.hs:249-251
+ *   suth       sutherlandConstant         src/SolutionDomain.hs:246-247
+ *   R          gasConstantR               src/SolutionDomain.hs:253-254
+ *   cv         specificHeatCv             src/SolutionDomain.hs:259-260
+ *   k          heatConductivityK          src/Main.hs:55-56
+ *   dye_f      dye diffusivity factor     src/Main.hs:148
+ *
+ * Slab decomposition (one handle per GPU): the handle owns nx planes.  ghost_lo / ghost_hi
+ * say whether a neighbouring slab exists below x = 0 / above x = nx-1; if so the handle keeps
+ * one extra plane on that side which the host fills before every sweep (cfd_halo_*), and the
+ * clamp-at-the-domain-edge rule of offsetPosition (src/SolutionDomain.hs:434-448) applies
+ * only on sides without a ghost plane.
+ */
+typedef struct cfd_params {
+    int32_t nx, ny, nz;
+    double dx, dy, dz;
+    double dt;
+    double lambda, suth, R, cv, k, dye_f;
+    int32_t device;      /* HIP device ordinal; -1 = the calling thread's current device */
+    int32_t flags;       /* CFD_FLAG_* */
+    int32_t ghost_lo;    /* 1 if a slab exists on the low-x side */
+    int32_t ghost_hi;    /* 1 if a slab exists on the high-x side */
+} cfd_params;
+
+typedef struct cfd_handle cfd_handle;
+
+/* Fills *p with the reference's shipped configuration (301 x 151 x 1, dt = 1e-5, air). */
+int cfd_default_params(cfd_params *p);
+
+/*
+ * Replaces initialGrid_adj's role as the state constructor (src/SolutionDomain.hs:308-353):
+ * builds the three time slots as copies of the given fields (":352 V.replicate storedSteps"),
+ * currModTime = currAbsTime = 0.  fields[i] has nx*ny*nz doubles (owned planes only, no
+ * ghosts); active has nx*ny*nz bytes, non-zero = the node's `active` flag.
+ */
+int cfd_create(const cfd_params *p, const double *const fields[CFD_NPROP],
+               const uint8_t *active, cfd_handle **out);
+
+void cfd_destroy(cfd_handle *h);
+
+/* runSingleStep (src/Main.hs:192-200), nsteps times: three sweeps, the first advancing the
+ * time slot, each followed by the time filter. */
+int cfd_step(cfd_handle *h, int nsteps);
+
+/* applyDiffEq_adj calcSteps_adj step_time (src/Main.hs:202-226): one forward-Euler sweep of
+ * the six equations from slot currModTime into slot currModTime+1 (step_time != 0) or back
+ * into slot currModTime (step_time == 0). */
+int cfd_sweep(cfd_handle *h, int step_time);
+
+/* correctPrevTime (src/Main.hs:228-258): slot t-1 <- pp + 0.5*(c - pp) with c = slot t,
+ * pp = slot t-2; a no-op while currAbsTime <= 1. */
+int cfd_time_filter(cfd_handle *h);
+
+/* totalDensity (src/Main.hs:269-270): sum of Density over slot currModTime-1 (owned planes).
+ * The reference folds sequentially; this is a tree reduction, so the last bits may differ. */
+int cfd_total_density(cfd_handle *h, double *out);
+
+/* Copies one time slot to the host.  slot_rel: 0 = currModTime, 1 = one back, 2 = two back
+ * (pushBackTime, src/SolutionDomain.hs:422-423).  out[i] receives nx*ny*nz doubles. */
+int cfd_read_fields(cfd_handle *h, int slot_rel, double *const out[CFD_NPROP]);
+
+/* currModTime and currAbsTime of the AdjGraph (src/SolutionDomain.hs:53-57). */
+int cfd_time(cfd_handle *h, int *curr_mod_time, int *curr_abs_time);
+
+const char *cfd_last_error(void);
+
+/* ---- slab halo exchange and overlap (no counterpart in the single-process reference) ---- */
+
+/*
+ * Device addresses and size of the planes a host exchanges before a sweep.  send_lo / send_hi
+ * are the first / last owned x-plane of the current slot; recv_lo / recv_hi are its ghost
+ * planes (NULL where the handle has no ghost on that side).  A plane holds every live field
+ * contiguously: plane_bytes = nfields * ny * nz * 8.
+ */
+int cfd_halo_planes(cfd_handle *h, void **send_lo, void **send_hi, void **recv_lo,
+                    void **recv_hi, size_t *plane_bytes);
+
+/* The HIP stream (hipStream_t) all of the handle's kernels run on. */
+int cfd_stream(cfd_handle *h, void **stream);
+
+/* Makes the handle launch on a caller-owned stream (hipStream_t; NULL = the device's default
+ * stream) from now on, e.g. the stream a host framework orders its collectives against. */
+int cfd_set_stream(cfd_handle *h, void *stream);
+
+/* Name of the sweep kernel the handle launches (for benchmark records). */
+const char *cfd_kernel_name(cfd_handle *h);
+
+/* Blocks until everything queued on the handle's stream has finished. */
+int cfd_sync(cfd_handle *h);
+
+/* Turns per-launch HIP-event timing of the sweep kernel on (enable != 0) or off (default). */
+int cfd_set_timing(cfd_handle *h, int enable);
+
+/*
+ * Measurement hook: device time of the sweep kernel, from HIP events recorded on the
+ * handle's stream around every sweep launch while timing was enabled.  total_ms = sum of
+ * kernel durations, launches = number of sweeps.  reset != 0 clears the accumulators
+ * after reading.
+ */
+int cfd_sweep_timing(cfd_handle *h, double *total_ms, int64_t *launches, int reset);
+
+/* Number of live fields the device holds per slot: 5 when nz == 1 and W is identically
+ * zero (W then stays exactly zero, so it is neither read nor written), else 6. */
+int cfd_live_fields(cfd_handle *h, int *nfields);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFD_HIP_H */

@@ -1,0 +1,118 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.
+
+Bars (stated per test):
+  * strict arithmetic vs Oracle B in t*sqrt(t) mode: BIT-EXACT (the kernels keep the reference's
+    operation order; +0/-0 are not distinguished);
+  * vs Oracle B in libm-pow mode (what GHC's ** calls): <= 1e-13 field-scale relative per sweep;
+  * totalDensity: <= 1e-12 relative (tree reduction vs sequential fold).
+"""
+import numpy as np
+import pytest
+
+from helpers import PROPS, bits_equal, oracle_params, rel_err, small_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_graph(params, fields, active, flags=0):
+    from cfd_amd.solver import AdjGraph
+    p = dict(params)
+    p["flags"] = flags
+    return AdjGraph(p, fields, active)
+
+
+def _oracle(params, fields, active, pow_mode):
+    from oracle import OracleB
+    return OracleB(oracle_params(params), fields, active, pow_mode=pow_mode, nthreads=4)
+
+
+def _assert_slots_bit_equal(g, b, what):
+    for rel in range(3):
+        fg, fb = g.read_fields(rel), b.read_fields(rel)
+        for k in range(7):
+            assert bits_equal(fg[k], fb[k]), "%s: slot -%d %s differs, max abs %.3e" % (
+                what, rel, PROPS[k], np.max(np.abs(fg[k] - fb[k])))
+
+
+@pytest.mark.parametrize("shape,seed,zero_v", [((12, 9), 1, False), ((31, 17), 2, True), ((64, 70), 3, False),
+                                                ((5, 130), 4, False), ((3, 3), 5, False), ((1, 1), 6, False),
+                                                ((2, 200), 7, True)])
+@pytest.mark.parametrize("flags", [1])
+def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags):
+    params, fields, active = small_case(shape[0], shape[1], 1, seed, zero_v)
+    g = _gpu_graph(params, fields, active, flags)
+    b = _oracle(params, fields, active, pow_mode=1)
+    assert g.live_fields == 5
+    for i, st in enumerate([True, False, False, True, False]):
+        g.sweep(st)
+        b.sweep(st)
+        assert (g.currModTime, g.currAbsTime) == b.time()
+        _assert_slots_bit_equal(g, b, "sweep %d" % i)
+
+
+@pytest.mark.parametrize("flags", [1])
+def test_steps_filter_and_density_2d(flags):
+    params, fields, active = small_case(40, 33, 1, 11)
+    g = _gpu_graph(params, fields, active, flags)
+    b = _oracle(params, fields, active, pow_mode=1)
+    for step in range(5):
+        g.step(1)
+        b.step(1)
+        assert (g.currModTime, g.currAbsTime) == b.time()
+        _assert_slots_bit_equal(g, b, "step %d" % step)
+        td, tb = g.total_density(), b.total_density()
+        assert abs(td - tb) <= 1e-12 * abs(tb)
+
+
+def test_single_sweep_vs_libm_pow_form():
+    """One sweep from identical state against the oracle in libm-pow mode (GHC's **):
+    <= 1e-13 field-scale relative.  (The t*sqrt(t) form differs from pow by a few ulp of mu.)"""
+    params, fields, active = small_case(40, 33, 1, 13)
+    g = _gpu_graph(params, fields, active, 1)
+    b0 = _oracle(params, fields, active, pow_mode=0)
+    g.sweep(True)
+    b0.sweep(True)
+    fg, f0 = g.read_fields(0), b0.read_fields(0)
+    for k in range(7):
+        assert rel_err(fg[k], f0[k]) <= 1e-13, PROPS[k]
+
+
+def test_filter_is_noop_until_second_step():
+    params, fields, active = small_case(9, 8, 1, 12)
+    g = _gpu_graph(params, fields, active, 1)
+    g.sweep(True)
+    before = g.read_fields(1)
+    g.time_filter()
+    after = g.read_fields(1)
+    for k in range(7):
+        assert bits_equal(before[k], after[k])
+
+
+def test_reference_case_five_steps():
+    """The shipped 301x151 case: five steps against Oracle B, and the step-0 totalDensity that
+    follows from the reference's constants (45,451 x 0.3 summed left to right)."""
+    from cfd_amd import cases
+    params, fields, active = cases.reference_case()
+    g = _gpu_graph(params, fields, active, 1)
+    b = _oracle(params, fields, active, pow_mode=1)
+    for step in range(5):
+        g.step(1)
+        b.step(1)
+        if step == 0:
+            assert b.total_density() == 13635.299999990304
+            assert abs(g.total_density() - 13635.299999990304) <= 1e-12 * 13635.3
+        _assert_slots_bit_equal(g, b, "step %d" % step)
+
+
+def test_error_paths():
+    from cfd_amd import _capi
+    from cfd_amd.solver import AdjGraph
+    params, fields, active = small_case(4, 4, 1, 1)
+    bad = dict(params)
+    bad["nx"] = 0
+    with pytest.raises(_capi.CfdError):
+        AdjGraph(bad, [f[:0] for f in fields], active[:0])
+    g = AdjGraph(params, fields, active)
+    with pytest.raises(_capi.CfdError):
+        g.read_fields(3)
