@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -65,6 +66,8 @@ struct cfd_handle {
     int device;
     int cmt, cat;
     SweepConsts K;
+    int chunk;              // x-planes per block of the tiled sweep
+    int variant;            // tiled-kernel launch shape (tuning knob)
     // sweep timing
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
@@ -136,6 +139,112 @@ sweep2d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict
     dp[(long)F2_U * ny] = act ? o[E2_U] : sp[(long)F2_U * ny];
     dp[(long)F2_V * ny] = act ? o[E2_V] : sp[(long)F2_V * ny];
     dp[(long)F2_DYE * ny] = act ? o[E2_DYE] : sp[(long)F2_DYE * ny];
+}
+
+// Tiled sweep ("march"): a block owns NT-2 adjacent columns (lanes run along y, the contiguous
+// index) plus one halo column on each side, and walks a chunk of x-planes.  Each thread keeps
+// its column's phase-A results for rows x-1, x, x+1 in registers, so the East/West neighbour
+// products never leave the thread; the North/South neighbour products of the current row cross
+// lanes through a double-buffered LDS tile.  Phase A is evaluated exactly once per cell (plus
+// the two halo columns and two extra rows per chunk), and every cell is read from HBM once.
+//
+//   iteration j:  phase A of row j  ->  publish its y-products in lds[j&1]
+//                 phase B of row j-1 (centre = row j-1, East = row j, West = row j-2,
+//                                     North/South = lds[(j-1)&1] of lanes t+1 / t-1)
+//                 one barrier
+constexpr int kShareY = 12;
+
+__device__ __forceinline__ void put_sy(double* __restrict__ l, int stride, const ShareY2& s) {
+    l[0 * stride] = s.aY;    l[1 * stride] = s.bY;    l[2 * stride] = s.bY23;  l[3 * stride] = s.tY;
+    l[4 * stride] = s.b2Y83; l[5 * stride] = s.bY83;  l[6 * stride] = s.a2Yh;  l[7 * stride] = s.gY;
+    l[8 * stride] = s.bE23;  l[9 * stride] = s.bW23;  l[10 * stride] = s.aE;   l[11 * stride] = s.aW;
+}
+
+__device__ __forceinline__ void get_sy(const double* __restrict__ l, int stride, ShareY2& s) {
+    s.aY = l[0 * stride];    s.bY = l[1 * stride];    s.bY23 = l[2 * stride];  s.tY = l[3 * stride];
+    s.b2Y83 = l[4 * stride]; s.bY83 = l[5 * stride];  s.a2Yh = l[6 * stride];  s.gY = l[7 * stride];
+    s.bE23 = l[8 * stride];  s.bW23 = l[9 * stride];  s.aE = l[10 * stride];   s.aW = l[11 * stride];
+}
+
+template <int NT, int MINW, bool PREFETCH>
+__global__ void __launch_bounds__(NT, MINW)
+sweep2d_march(SweepConsts K, const double* __restrict__ src, double* __restrict__ dst,
+              const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch) {
+    __shared__ double lds[2][kShareY][NT];
+    const int t = threadIdx.x;
+    const int y = (int)blockIdx.x * (NT - 2) - 1 + t;
+    const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
+    const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
+    const bool writer = t >= 1 && t <= NT - 2 && y < ny;
+    const int xs = (int)blockIdx.y * ch;
+    const int xe = xs + ch < nx ? xs + ch : nx;
+    const int j0 = xs - 1 > xlo ? xs - 1 : xlo;      // first and last row whose phase A is needed
+    const int j1 = xe < xhi ? xe : xhi;
+    const long plane5 = (long)NF2 * ny;
+    auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
+
+    double rw[NF2], rc[NF2], re[NF2], rn[NF2], rs[NF2];
+    load5(src, plane5, ny, clampx(j0 - 1), cy, rw);
+    load5(src, plane5, ny, j0, cy, rc);
+    load5(src, plane5, ny, clampx(j0 + 1), cy, re);
+    load5(src, plane5, ny, j0, yn, rn);
+    load5(src, plane5, ny, j0, ys, rs);
+
+    PhaseA2 Ac;      // phase A of row j-1
+    ShareX2 Xw;      // x-products of row j-2
+
+    auto emit = [&](int x, const ShareX2& XE) {
+        // phase B of row x; Ac holds its phase A, lds[x&1] its neighbours' y-products
+        ShareY2 YN, YS;
+        const int tn = t + 1 > NT - 1 ? NT - 1 : t + 1, tsn = t - 1 < 0 ? 0 : t - 1;
+        get_sy(&lds[x & 1][0][tn], NT, YN);
+        get_sy(&lds[x & 1][0][tsn], NT, YS);
+        ShareX2 XW = Xw;
+        if (x - 1 < xlo) XW = Ac.sx;              // clamped West neighbour is the cell itself
+        double o[5];
+        phaseB2(K, Ac, XE, XW, YN, YS, o);
+        if (writer) {
+            const bool act = active[(long)x * ny + y] != 0;
+            const double* sp = src + (long)x * plane5 + y;
+            double* dp = dst + (long)x * plane5 + y;
+            dp[(long)F2_RHO * ny] = o[E2_RHO];
+            dp[(long)F2_T * ny] = o[E2_T];
+            dp[(long)F2_U * ny] = act ? o[E2_U] : sp[(long)F2_U * ny];
+            dp[(long)F2_V * ny] = act ? o[E2_V] : sp[(long)F2_V * ny];
+            dp[(long)F2_DYE * ny] = act ? o[E2_DYE] : sp[(long)F2_DYE * ny];
+        }
+    };
+
+    for (int j = j0; j <= j1; ++j) {
+        // prefetch the raw values the next iteration needs
+        double re2[NF2], rn2[NF2], rs2[NF2];
+        const int jn = clampx(j + 1);
+        if (PREFETCH) {
+            load5(src, plane5, ny, clampx(j + 2), cy, re2);
+            load5(src, plane5, ny, jn, yn, rn2);
+            load5(src, plane5, ny, jn, ys, rs2);
+        }
+
+        PhaseA2 An;
+        phaseA2(K, rc, re, rw, rn, rs, An);
+        put_sy(&lds[j & 1][0][t], NT, An.sy);
+        const int x = j - 1;
+        if (x >= xs) emit(x, An.sx);               // block-uniform
+        __syncthreads();
+        Xw = Ac.sx;
+        Ac = An;
+        if (!PREFETCH) {
+            load5(src, plane5, ny, clampx(j + 2), cy, re2);
+            load5(src, plane5, ny, jn, yn, rn2);
+            load5(src, plane5, ny, jn, ys, rs2);
+        }
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) {
+            rw[f] = rc[f]; rc[f] = re[f]; re[f] = re2[f]; rn[f] = rn2[f]; rs[f] = rs2[f];
+        }
+    }
+    // last owned row of the domain: its clamped East neighbour is the cell itself
+    if (j1 < xe) emit(xe - 1, Ac.sx);
 }
 
 // correctPrevTime: prev <- pp + 0.5*(c - pp); Density and Temperature in every cell, the
@@ -210,10 +319,29 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
         }
         HIP_TRY(hipEventRecord(ev.a, h->stream));
     }
-    if (h->two_d) {
+    if (h->two_d && (p.flags & CFD_FLAG_SIMPLE_KERNEL)) {
         dim3 block(64), grid((p.ny + 63) / 64, p.nx);
         hipLaunchKernelGGL(sweep2d_simple, grid, block, 0, h->stream, h->K, src, dst,
                            h->d_active + h->plane, p.nx, p.ny, xlo, xhi);
+    } else if (h->two_d) {
+        const int ch = h->chunk;
+#define LAUNCH_MARCH(NT, MINW, PF)                                                                 \
+    do {                                                                                           \
+        dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (p.nx + ch - 1) / ch);                    \
+        hipLaunchKernelGGL((sweep2d_march<NT, MINW, PF>), grid, block, 0, h->stream, h->K, src,    \
+                           dst, h->d_active + h->plane, p.nx, p.ny, xlo, xhi, ch);                 \
+    } while (0)
+        switch (h->variant) {
+            case 1: LAUNCH_MARCH(256, 2, true); break;
+            case 2: LAUNCH_MARCH(256, 2, false); break;
+            case 3: LAUNCH_MARCH(128, 1, true); break;
+            case 4: LAUNCH_MARCH(128, 1, false); break;
+            case 5: LAUNCH_MARCH(64, 1, true); break;
+            case 6: LAUNCH_MARCH(64, 1, false); break;
+            case 7: LAUNCH_MARCH(256, 1, false); break;
+            default: LAUNCH_MARCH(256, 1, true); break;
+        }
+#undef LAUNCH_MARCH
     } else {
         return fail(CFD_E_STATE, "3-D sweep kernel not built into this library yet");
     }
@@ -302,6 +430,10 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->slot_elems = (size_t)h->nf * (p->nx + 2) * h->plane;
     h->K = make_consts(p->dx, p->dy, p->dz, p->dt, p->lambda, p->suth, p->R, p->cv, p->k, p->dye_f);
     h->cmt = 0; h->cat = 0;
+    h->chunk = 32;
+    if (const char* e = getenv("CFD_CHUNK")) { int v = atoi(e); if (v >= 1) h->chunk = v; }
+    h->variant = 2;
+    if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
     h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;
     h->timing = false; h->t_ms = 0.0; h->t_launches = 0;
@@ -471,7 +603,8 @@ int cfd_set_stream(cfd_handle* h, void* stream) {
 
 const char* cfd_kernel_name(cfd_handle* h) {
     if (!h) return "";
-    return h->two_d ? "sweep2d_simple" : "sweep3d";
+    if (!h->two_d) return "sweep3d";
+    return (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) ? "sweep2d_simple" : "sweep2d_march";
 }
 
 int cfd_sync(cfd_handle* h) {

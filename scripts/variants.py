@@ -1,0 +1,19 @@
+"""Times the sweep kernel for several launch shapes (tuning aid).  usage: variants.py v:chunk ..."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cfd_amd import cases
+from cfd_amd.solver import AdjGraph
+nx = int(os.environ.get("NX", 4096)); ny = int(os.environ.get("NY", 4096))
+params, fields, active = cases.synthetic_2d(nx, ny, seed=1)
+for spec in sys.argv[1:]:
+    v, ch = spec.split(":")
+    os.environ["CFD_VARIANT"] = v; os.environ["CFD_CHUNK"] = ch
+    p = dict(params); p["flags"] = 1 if v == "s" else 0
+    if v == "s": os.environ["CFD_VARIANT"] = "0"
+    g = AdjGraph(p, fields, active)
+    for _ in range(3): g.sweep(False)
+    g.set_timing(True); g.sweep_timing()
+    for _ in range(10): g.sweep(False)
+    ms, n = g.sweep_timing()
+    print("variant %s chunk %s: %.3f ms/sweep  %.2f Gcell/s  %.0f GB/s" % (v, ch, ms / n, nx * ny / (ms / n) / 1e6, nx * ny * 81 / (ms / n) / 1e6), flush=True)
+    g.close()

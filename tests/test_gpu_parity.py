@@ -37,9 +37,12 @@ def _assert_slots_bit_equal(g, b, what):
 
 @pytest.mark.parametrize("shape,seed,zero_v", [((12, 9), 1, False), ((31, 17), 2, True), ((64, 70), 3, False),
                                                 ((5, 130), 4, False), ((3, 3), 5, False), ((1, 1), 6, False),
-                                                ((2, 200), 7, True)])
-@pytest.mark.parametrize("flags", [1])
-def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags):
+                                                ((2, 200), 7, True), ((70, 300), 8, False),
+                                                ((37, 254), 9, False), ((33, 255), 10, False),
+                                                ((9, 509), 11, False)])
+@pytest.mark.parametrize("flags,chunk", [(1, 32), (0, 32), (0, 1), (0, 5)])
+def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags, chunk, monkeypatch):
+    monkeypatch.setenv("CFD_CHUNK", str(chunk))
     params, fields, active = small_case(shape[0], shape[1], 1, seed, zero_v)
     g = _gpu_graph(params, fields, active, flags)
     b = _oracle(params, fields, active, pow_mode=1)
@@ -51,7 +54,7 @@ def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags):
         _assert_slots_bit_equal(g, b, "sweep %d" % i)
 
 
-@pytest.mark.parametrize("flags", [1])
+@pytest.mark.parametrize("flags", [0, 1])
 def test_steps_filter_and_density_2d(flags):
     params, fields, active = small_case(40, 33, 1, 11)
     g = _gpu_graph(params, fields, active, flags)
@@ -94,7 +97,7 @@ def test_reference_case_five_steps():
     follows from the reference's constants (45,451 x 0.3 summed left to right)."""
     from cfd_amd import cases
     params, fields, active = cases.reference_case()
-    g = _gpu_graph(params, fields, active, 1)
+    g = _gpu_graph(params, fields, active, 0)
     b = _oracle(params, fields, active, pow_mode=1)
     for step in range(5):
         g.step(1)
@@ -103,6 +106,23 @@ def test_reference_case_five_steps():
             assert b.total_density() == 13635.299999990304
             assert abs(g.total_density() - 13635.299999990304) <= 1e-12 * 13635.3
         _assert_slots_bit_equal(g, b, "step %d" % step)
+
+
+def test_tiled_kernel_matches_per_cell_kernel_at_size():
+    """Beyond what the CPU oracle reaches in seconds: the tiled kernel against the one-thread-per-cell
+    kernel (itself bit-exact against the oracle above) on a 1500 x 1100 grid, three steps, bit-exact."""
+    from cfd_amd import cases
+    params, fields, active = cases.synthetic_2d(1500, 1100, seed=5)
+    ga = _gpu_graph(params, fields, active, 0)
+    gb = _gpu_graph(params, fields, active, 1)
+    for step in range(3):
+        ga.step(1)
+        gb.step(1)
+        for rel in range(3):
+            fa, fb = ga.read_fields(rel), gb.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(fa[k], fb[k]), (step, rel, PROPS[k])
+    assert abs(ga.total_density() - gb.total_density()) == 0.0
 
 
 def test_error_paths():
