@@ -56,6 +56,9 @@ class GpuBackend:
             out.append(t)
         return out
 
+    def halo_commit(self):
+        """Received planes land directly in the time slot; nothing to unpack."""
+
     def scalar_tensor(self, v):
         return self._torch.tensor([v], dtype=self._torch.float64, device="cuda")
 
@@ -84,6 +87,7 @@ class DistComm:
             ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        backend.halo_commit()
 
     def all_sum(self, backend, v):
         if self.world == 1:
@@ -109,6 +113,7 @@ class LocalComm:
             recv_lo.copy_(self.peers[me - 1].backend.halo_tensors()[1])
         if me < len(self.peers) - 1:
             recv_hi.copy_(self.peers[me + 1].backend.halo_tensors()[0])
+        backend.halo_commit()
 
     def all_sum(self, backend, v):
         raise NotImplementedError("sum over virtual ranks is done by the caller")

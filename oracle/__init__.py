@@ -50,6 +50,8 @@ def lib():
         L.ob_total_density.argtypes = [ctypes.c_void_p]
         L.ob_read_fields.argtypes = [ctypes.c_void_p, ctypes.c_int, PP]
         L.ob_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.ob_slot_ptr.restype = ctypes.POINTER(ctypes.c_double)
+        L.ob_slot_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.ob_superbee.restype = ctypes.c_double
         L.ob_superbee.argtypes = [ctypes.c_double, ctypes.c_double]
         L.ob_mu.restype = ctypes.c_double
@@ -95,6 +97,10 @@ class OracleB:
         out = [np.empty(self.n, dtype=np.float64) for _ in range(7)]
         self.L.ob_read_fields(self.h, slot_rel, _ptr_array(out))
         return out
+
+    def slot_view(self, slot_rel, q):
+        """Writable numpy view of live field q (U V W Density Temperature Dye) of slot cmt-slot_rel."""
+        return np.ctypeslib.as_array(self.L.ob_slot_ptr(self.h, slot_rel, q), shape=(self.n,))
 
     def time(self):
         a, b = ctypes.c_int(), ctypes.c_int()

@@ -263,12 +263,14 @@ def makePositions(maxes):              # :388-392 ; first coordinate slowest
     return coords
 
 
-def build_graph(maxPos, gridSize, fields, active):
+def build_graph(maxPos, gridSize, fields, active, cellLength=None):
     """Equivalent of initialGrid_adj (src/SolutionDomain.hs:308-353) for caller-supplied
     values: `fields` is 7 sequences in propIndex order (U,V,W,Density,Temperature,Mew,Dye),
     `active` a sequence of bools, both in node order (x slowest, z fastest).
-    Geometry follows cellLength (:150-151) and the avMap/slMap folds (:279-286)."""
-    cellLength = [fdiv(gridSize[i], float(maxPos[i] + 1)) for i in range(3)]
+    Geometry follows cellLength (:150-151) and the avMap/slMap folds (:279-286); a caller that
+    already holds the three cell lengths passes them as `cellLength` (gridSize is then unused)."""
+    if cellLength is None:
+        cellLength = [fdiv(gridSize[i], float(maxPos[i] + 1)) for i in range(3)]
     slMap = {d: cellLength[dirIndex(d)] for d in DIRS_FROM_X}
     avMap = {}
     for s in SIDES_FROM_EAST:

@@ -420,6 +420,13 @@ void ob_read_fields(const ob_state *s, int slot_rel, double *const out7[7]) {
 
 void ob_time(const ob_state *s, int *cmt, int *cat) { *cmt = s->cmt; *cat = s->cat; }
 
+/* Address of one live field (0..5 = U V W Density Temperature Dye) of slot cmt-slot_rel, so that a
+ * test harness can overwrite halo planes in place. */
+double *ob_slot_ptr(ob_state *s, int slot_rel, int q) {
+    int t = ((s->cmt - slot_rel) % 3 + 3) % 3;
+    return s->slot[t][q];
+}
+
 /* exposed for unit tests */
 double ob_superbee(double a, double b) { return superbee(a, b); }
 double ob_mu(const ob_params *p, double t) { return mu_of(p, t); }

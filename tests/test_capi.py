@@ -1,0 +1,63 @@
+"""The C-ABI library loads, exports every symbol include/cfd_hip.h declares, and fails loudly
+(no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cfd_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    with open(os.path.join(ROOT, "include", "cfd_hip.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(cfd_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    syms = header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(_capi.EXPORTS) == syms
+
+
+def test_default_params_are_the_shipped_configuration():
+    lib = _capi.load()
+    p = _capi.CfdParams()
+    assert lib.cfd_default_params(ctypes.byref(p)) == 0
+    assert (p.nx, p.ny, p.nz) == (301, 151, 1)
+    assert p.dx == 1.6 / 301 and p.dy == 0.8 / 151 and p.dz == 1.0
+    assert p.dt == 0.00001 and p.R == 289.0 and p.cv == 716.0 and p.k == 0.025 and p.dye_f == 0.001
+    assert p.lambda_ == 0.010299990531505463
+    assert lib.cfd_default_params(None) == _capi.CFD_E_ARG
+
+
+def test_params_struct_layout_matches_header():
+    # 3 x int32 (+4 pad), 10 doubles, 4 x int32
+    assert ctypes.sizeof(_capi.CfdParams) == 16 + 80 + 16
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = _capi.load()
+    assert lib.cfd_sweep(None, 1) == _capi.CFD_E_ARG
+    assert b"null" in lib.cfd_last_error()
+    assert lib.cfd_step(None, 1) == _capi.CFD_E_ARG
+    assert lib.cfd_time_filter(None) == _capi.CFD_E_ARG
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from cfd_amd import cases
+    from cfd_amd.solver import AdjGraph
+    params, fields, active = cases.synthetic_2d(8, 8)
+    with pytest.raises(_capi.CfdError) as e:
+        AdjGraph(params, fields, active)
+    assert e.value.code == _capi.CFD_E_DEVICE

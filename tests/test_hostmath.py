@@ -1,0 +1,49 @@
+"""The kernels' per-cell arithmetic (cfd_amd/csrc/sweep_math.h) compiled for the host and checked
+bit-for-bit against Oracle B: pins the operation order of the HIP code without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import bits_equal, oracle_params, small_case
+from oracle import OracleB
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hm():
+    d = os.path.join(HERE, "hostmath")
+    subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(os.path.join(d, "libhostmath.so"))
+
+
+def _ptrs(arrs):
+    a = (ctypes.c_void_p * len(arrs))()
+    for i, x in enumerate(arrs):
+        a[i] = x.ctypes.data
+    return a
+
+
+@pytest.mark.parametrize("shape,seed,zero_v", [((12, 9), 1, False), ((31, 17), 2, True), ((64, 40), 3, False),
+                                                ((1, 1), 4, False), ((2, 5), 5, False)])
+def test_sweep2d_math_bit_exact(hm, shape, seed, zero_v):
+    nx, ny = shape
+    params, fields, active = small_case(nx, ny, 1, seed, zero_v)
+    p = oracle_params(params)
+    b = OracleB(p, fields, active, pow_mode=1)
+    cur = [fields[i].copy() for i in (0, 1, 3, 4, 6)]
+    d = ctypes.c_double
+    for sweep in range(4):
+        b.sweep(sweep == 0)
+        out = [np.empty(nx * ny) for _ in range(5)]
+        hm.hm_sweep2d(nx, ny, d(p["dx"]), d(p["dy"]), d(p["dz"]), d(p["dt"]), d(p["lambda_"]), d(p["suth"]),
+                      d(p["R"]), d(p["cv"]), d(p["k"]), d(p["dye_f"]), _ptrs(cur),
+                      active.ctypes.data_as(ctypes.c_void_p), _ptrs(out))
+        fb = b.read_fields(0)
+        for j, i in enumerate((0, 1, 3, 4, 6)):
+            assert bits_equal(out[j], fb[i]), (sweep, i)
+        assert np.all(fb[2] == 0)
+        cur = out

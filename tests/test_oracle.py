@@ -1,0 +1,187 @@
+"""CPU tests of the oracles.
+
+Pins, in order of authority:
+  1. the two known answers the reference itself records (src/old test.txt:2-3) -- the ONLY
+     reference-owned results for this path; the sweep itself is unpinned by the reference;
+  2. oracle_a (literal term algebra) == committed golden fixtures (regression);
+  3. oracle_b (closed form, libm pow) == golden fixtures, BIT-EXACT;
+  4. oracle_b in t*sqrt(t) mode vs libm-pow mode: <= 1e-13 field-scale relative per sweep.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import PROPS, bits_equal, oracle_params, rel_err, small_case
+from oracle import OracleB, lib, oracle_a as A
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["case_12x9x1", "case_7x6x5", "case_3x3x3_zero_vw", "case_8x7x1_zero_v"]
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    params = json.loads(str(z["params"]))
+    fields = [z["in_%d" % k] for k in range(7)]
+    return z, params, fields, z["active"]
+
+
+def kat():
+    with open(os.path.join(GOLD, "kat.json")) as f:
+        return json.load(f)
+
+
+# ---- 1. reference-owned known answers --------------------------------------------------------
+def test_kat_solve_unknown_test_equation():
+    """src/Main.hs:79-85 evaluated by solveUnknown; expected value recorded at src/old test.txt:2."""
+    got = A.solveUnknown(A.testEquation(), (0, 0), None)
+    assert got == kat()["solveUnknown_testEquation"] == 0.5866666666666668
+
+
+def test_kat_distribute_multiply_test_terms():
+    """src/Main.hs:309 through distributeMultiply _ 2; expected list recorded at src/old test.txt:3."""
+    got = A.distributeMultiply(A.testTerms(), 2.0)
+    flat = [["Unknown", t.coeff] if isinstance(t, A.Unknown) else ["Constant", t.val] for t in got]
+    assert flat == kat()["distributeMultiply_testTerms_2"]
+
+
+def test_constants():
+    k = kat()
+    assert A.sutherlandLambda == k["sutherlandLambda"] == 0.010299990531505463
+    assert A.gasConstantR == 289.0
+    assert -(2.0 / 3.0) == -0.6666666666666666
+    assert (8.0 / 3.0) / 2.0 == 1.3333333333333333
+
+
+def test_term_counts_match_reference_dump():
+    """src/old test.txt:12,18,24 shows 18 approxDeriv terms on each momentum right-hand side; the
+    instantiated equations have: continuity 8+1, momentum 10+18, dye 8+6, energy 14+60 terms."""
+    params, fields, active = small_case(3, 3, 3, seed=1)
+    g = A.build_graph((2, 2, 2), None, fields, active, cellLength=[params["dx"], params["dy"], params["dz"]])
+    counts = {}
+    for eq, _ in A.calcSteps_adj:
+        inst = A.getDiscEqInstance(eq(g), (13, 0))
+        counts[inst.unknownProperty] = (len(inst.lhs), len(inst.rhs))
+    assert counts[A.DENSITY] == (8, 1)
+    assert counts[A.U] == counts[A.V] == counts[A.W] == (10, 18)
+    assert counts[A.DYE] == (8, 6)
+    assert counts[A.TEMPERATURE] == (14, 60)
+
+
+# ---- limiter -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("a,b,want", [
+    (1.0, 2.0, 2.0), (2.0, 1.0, 2.0), (1.0, 3.0, 2.0), (3.0, 1.0, 2.0), (1.0, 1.0, 1.0),
+    (-1.0, -2.0, -2.0), (-1.0, -3.0, -2.0), (-3.0, -1.0, -2.0), (1.0, -1.0, 0.0), (-1.0, 1.0, 0.0),
+    (0.0, 1.0, 0.0), (1.0, 0.0, 0.0), (-0.0, -1.0, 0.0), (0.0, 0.0, 0.0), (1e-300, 1e-300, 1e-300),
+    (5e-324, 1.0, 1e-323), (1e308, 1e308, 1e308),
+])
+def test_superbee_table(a, b, want):
+    assert A.superbee(a, b) == want
+    assert lib().ob_superbee(a, b) == want
+
+
+def test_superbee_random_a_vs_b():
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        a, b = rng.normal(size=2) * 10.0 ** rng.integers(-8, 8)
+        assert A.superbee(a, b) == lib().ob_superbee(a, b)
+        m = min(max(abs(a), abs(b)), 2 * min(abs(a), abs(b)))
+        assert A.superbee(a, b) == (math.copysign(m, a) if a * b > 0 else 0.0)
+
+
+# ---- 2./3. golden fixtures -------------------------------------------------------------------
+def test_oracle_a_regression_one_sweep():
+    z, params, fields, active = load_case("case_12x9x1")
+    nx, ny, nz = params["nx"], params["ny"], params["nz"]
+    g = A.build_graph((nx - 1, ny - 1, nz - 1), None, fields, active,
+                      cellLength=[params["dx"], params["dy"], params["dz"]])
+    g = A.applyDiffEq_adj(A.calcSteps_adj, True, g)
+    for k, f in enumerate(A.slot_fields(g, 0)):
+        assert bits_equal(np.array(f), z["sweep0_%d" % k]), PROPS[k]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_b_matches_golden_bit_exact(name):
+    z, params, fields, active = load_case(name)
+    b = OracleB(params, fields, active, pow_mode=0)
+    for i, st in enumerate(z["sweep_flags"]):
+        b.sweep(bool(st))
+        fb = b.read_fields(0)
+        for k in range(7):
+            assert bits_equal(fb[k], z["sweep%d_%d" % (i, k)]), (name, i, PROPS[k])
+    b = OracleB(params, fields, active, pow_mode=0)
+    for s in range(len(z["step_density"])):
+        b.step(1)
+        assert b.time() == tuple(z["step_times"][s])
+        assert b.total_density() == z["step_density"][s]
+        for rel in range(3):
+            fb = b.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(fb[k], z["step%d_slot%d_%d" % (s, rel, k)]), (name, s, rel, PROPS[k])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sqrt_form_within_1e13_of_pow_form_per_sweep(name):
+    """t*sqrt(t) (what the GPU evaluates) against libm pow (what GHC's ** calls), one sweep from
+    identical state: <= 1e-13 field-scale relative."""
+    z, params, fields, active = load_case(name)
+    b = OracleB(params, fields, active, pow_mode=1)
+    b.sweep(True)
+    fb = b.read_fields(0)
+    for k in range(7):
+        assert rel_err(fb[k], z["sweep0_%d" % k]) <= 1e-13, (name, PROPS[k])
+
+
+def test_w_stays_exactly_zero_in_2d():
+    z, params, fields, active = load_case("case_12x9x1")
+    for s in range(3):
+        for rel in range(3):
+            w = z["step%d_slot%d_2" % (s, rel)]
+            assert np.all(w == 0) and not np.any(np.signbit(w))
+
+
+def test_filter_after_first_two_sweeps_is_dead():
+    """correctPrevTime runs after each of the three sweeps of a step, but only the last call's
+    result survives; the library launches it once per step."""
+    params, fields, active = small_case(10, 8, 1, seed=3)
+    a = OracleB(oracle_params(params), fields, active, pow_mode=0)
+    b = OracleB(oracle_params(params), fields, active, pow_mode=0)
+    for _ in range(4):
+        a.step(1)
+        b.sweep(True); b.sweep(False); b.sweep(False); b.time_filter()
+        for rel in range(3):
+            fa, fb = a.read_fields(rel), b.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(fa[k], fb[k])
+
+
+# ---- shipped case -----------------------------------------------------------------------------
+def test_shipped_case_stdout_and_step0_density():
+    from cfd_amd import cases
+    from cfd_amd.solver import _hs_show_double
+    params, fields, active = cases.reference_case()
+    assert params["nx"] * params["ny"] * params["nz"] == 45451
+    assert int((active == 0).sum()) == 151 + 400
+    b = OracleB(oracle_params(params), fields, active, pow_mode=0, nthreads=4)
+    with open(os.path.join(GOLD, "shipped_case_stdout_5steps.txt")) as f:
+        want = f.read()
+    got = ""
+    for step in range(5):
+        b.step(1)
+        cmt, cat = b.time()
+        if step == 0:
+            assert b.total_density() == kat()["totalDensity_step0_shipped_case"]
+        got += "%d\nstep: %d\ntimeLevel: %d\ntimeLevelAbsolute: %d\ntotalDensity: %s\n \n" % (
+            b.n, step, cmt, cat, _hs_show_double(b.total_density()))
+    assert got == want
+
+
+def test_haskell_show_double():
+    from cfd_amd.solver import _hs_show_double as sh
+    assert sh(13635.299999990304) == "13635.299999990304"
+    assert sh(1e-4) == "1.0e-4" and sh(-1e-4) == "-1.0e-4"
+    assert sh(1.0496787532449728e-3) == "1.0496787532449728e-3"     # form seen in src/old test.txt:48
+    assert sh(0.0) == "0.0" and sh(-0.0) == "-0.0" and sh(15.0) == "15.0"
+    assert sh(12345678.9) == "1.23456789e7"
