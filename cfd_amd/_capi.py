@@ -45,6 +45,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # A process must hold ONE HIP runtime.  PyTorch ships its own copy of libamdhip64 under the same
+    # soname as the system one this library links against; whichever is loaded first serves both.
+    # If the system copy came first, torch would later find no GPU -- so when torch is installed,
+    # let it load its runtime before this library binds to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libcfdhip.so is not built (%s); run `make -C cfd_amd/csrc` or __graft_entry__.build(). "
