@@ -141,6 +141,62 @@ sweep2d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict
     dp[(long)F2_DYE * ny] = act ? o[E2_DYE] : sp[(long)F2_DYE * ny];
 }
 
+// General 3-D sweep, one thread per cell (lanes along z, then y).  Each thread evaluates phase A
+// for its cell and the parts of its six face neighbours' phase A that it differences.
+__device__ __forceinline__ void phaseA3_at(const SweepConsts& K, const double* __restrict__ src, long plane,
+                                           int ny, int nz, int x, int y, int z, int xlo, int xhi, PhaseA3& o) {
+    const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
+    const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
+    const int zt = z + 1 > nz - 1 ? nz - 1 : z + 1, zb = z - 1 < 0 ? 0 : z - 1;
+    const long o6[7] = {(long)x * NF3 * plane + (long)y * nz + z,
+                        (long)xe * NF3 * plane + (long)y * nz + z,  (long)xw * NF3 * plane + (long)y * nz + z,
+                        (long)x * NF3 * plane + (long)yn * nz + z,  (long)x * NF3 * plane + (long)ys * nz + z,
+                        (long)x * NF3 * plane + (long)y * nz + zt,  (long)x * NF3 * plane + (long)y * nz + zb};
+    double c[NF3], nb[6][NF3];
+#pragma unroll
+    for (int f = 0; f < NF3; ++f) {
+        c[f] = src[o6[0] + (long)f * plane];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) nb[s][f] = src[o6[s + 1] + (long)f * plane];
+    }
+    phaseA3(K, c, nb, o);
+}
+
+__global__ void __launch_bounds__(64)
+sweep3d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict__ dst,
+               const uint8_t* __restrict__ active, int nx, int ny, int nz, int xlo, int xhi) {
+    const long plane = (long)ny * nz;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.y;
+    if (i >= plane || x >= nx) return;
+    const int y = (int)(i / nz), z = (int)(i - (long)y * nz);
+    const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
+    const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
+    const int zt = z + 1 > nz - 1 ? nz - 1 : z + 1, zb = z - 1 < 0 ? 0 : z - 1;
+    PhaseA3 C, T;
+    ShareX3 XP, XM;
+    ShareY3 YP, YM;
+    ShareZ3 ZP, ZM;
+    phaseA3_at(K, src, plane, ny, nz, x, y, z, xlo, xhi, C);
+    phaseA3_at(K, src, plane, ny, nz, xe, y, z, xlo, xhi, T);  XP = T.sx;
+    phaseA3_at(K, src, plane, ny, nz, xw, y, z, xlo, xhi, T);  XM = T.sx;
+    phaseA3_at(K, src, plane, ny, nz, x, yn, z, xlo, xhi, T);  YP = T.sy;
+    phaseA3_at(K, src, plane, ny, nz, x, ys, z, xlo, xhi, T);  YM = T.sy;
+    phaseA3_at(K, src, plane, ny, nz, x, y, zt, xlo, xhi, T);  ZP = T.sz;
+    phaseA3_at(K, src, plane, ny, nz, x, y, zb, xlo, xhi, T);  ZM = T.sz;
+    double o[NE3];
+    phaseB3(K, C, XP, XM, YP, YM, ZP, ZM, o);
+    const bool act = active[(long)x * plane + i] != 0;
+    const double* sp = src + (long)x * NF3 * plane + i;
+    double* dp = dst + (long)x * NF3 * plane + i;
+    dp[(long)F3_RHO * plane] = o[E3_RHO];
+    dp[(long)F3_T * plane] = o[E3_T];
+    dp[(long)F3_U * plane] = act ? o[E3_U] : sp[(long)F3_U * plane];
+    dp[(long)F3_V * plane] = act ? o[E3_V] : sp[(long)F3_V * plane];
+    dp[(long)F3_W * plane] = act ? o[E3_W] : sp[(long)F3_W * plane];
+    dp[(long)F3_DYE * plane] = act ? o[E3_DYE] : sp[(long)F3_DYE * plane];
+}
+
 // Tiled sweep ("march"): a block owns NT-2 adjacent columns (lanes run along y, the contiguous
 // index) plus one halo column on each side, and walks a chunk of x-planes.  Each thread keeps
 // its column's phase-A results for rows x-1, x, x+1 in registers, so the East/West neighbour
@@ -343,7 +399,9 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
         }
 #undef LAUNCH_MARCH
     } else {
-        return fail(CFD_E_STATE, "3-D sweep kernel not built into this library yet");
+        dim3 block(64), grid((unsigned)((h->plane + 63) / 64), p.nx);
+        hipLaunchKernelGGL(sweep3d_simple, grid, block, 0, h->stream, h->K, src, dst,
+                           h->d_active + h->plane, p.nx, p.ny, p.nz, xlo, xhi);
     }
     HIP_TRY(hipGetLastError());
     if (h->timing) {
@@ -603,7 +661,7 @@ int cfd_set_stream(cfd_handle* h, void* stream) {
 
 const char* cfd_kernel_name(cfd_handle* h) {
     if (!h) return "";
-    if (!h->two_d) return "sweep3d";
+    if (!h->two_d) return "sweep3d_simple";
     return (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) ? "sweep2d_simple" : "sweep2d_march";
 }
 

@@ -315,4 +315,254 @@ CFD_HD void phaseB2(const SweepConsts& k, const PhaseA2& C, const ShareX2& XE, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// General 3-D case.  Field order of the 3-D arrays: U, V, W, Density, Temperature, Dye.
+// Directions d = 0,1,2 (X,Y,Z); faces of direction d: index 0 = upper (East/North/Top),
+// 1 = lower (West/South/Bottom).  Also valid for nz == 1 with W != 0 (Top/Bottom neighbours are
+// then the cell itself).
+// ------------------------------------------------------------------------------------------
+enum { F3_U = 0, F3_V, F3_W, F3_RHO, F3_T, F3_DYE, NF3 };
+enum { E3_RHO = 0, E3_U, E3_V, E3_W, E3_T, E3_DYE, NE3 };
+
+// Centre products scaled by (A_d dt) for one direction d; differenced by the cell and its +-d
+// neighbours.  m[c] = mu u_c; sqh[c] = ((mu u_c) mu) u_c * 0.5 (used for c != d).
+struct SameDir3 {
+    double m[3];
+    double m23;     // (mu u_d) * m23
+    double t;       // T * k
+    double sq83;    // (((mu u_d) mu) u_d) * c83h
+    double m83;     // (mu u_d) * c83n
+    double sqh[3];
+    double g;       // (mu Dye) * dyef
+};
+
+// What the +-X neighbours difference: this cell's products on its Y and Z faces.
+struct ShareX3 {
+    SameDir3 s;
+    double yMuV[2], yMuU23[2], yMuUV[2], yMuU[2], yV[2];
+    double zMuW[2], zMuU23[2], zMuUW[2], zMuU[2], zW[2];
+};
+// What the +-Y neighbours difference: products on the X and Z faces.
+struct ShareY3 {
+    SameDir3 s;
+    double xMuV23[2], xMuU[2];
+    double zMuW[2], zMuV23[2];
+};
+// What the +-Z neighbours difference: products on the X and Y faces.
+struct ShareZ3 {
+    SameDir3 s;
+    double xMuW23[2], xMuU[2];
+    double yMuW23[2], yMuV[2], yMuWV[2], yMuW[2], yV[2];
+};
+
+struct PhaseA3 {
+    double lhs[NE3];
+    double aU[NE3];
+    ShareX3 sx;
+    ShareY3 sy;
+    ShareZ3 sz;
+};
+
+// c: the cell's six stored values; nb[2*d+s]: those of its clamped neighbour on face (d, s).
+CFD_HD void phaseA3(const SweepConsts& k, const double c[NF3], const double nb[6][NF3], PhaseA3& o) {
+    const double A[3] = {k.Ae, k.An, k.At};
+    const double dt = k.dt;
+    double f[3][2][NF3];          // limited face values
+    for (int d = 0; d < 3; ++d)
+        for (int q = 0; q < NF3; ++q) {
+            const double h = half_slope(nb[2 * d][q], c[q], nb[2 * d + 1][q]);
+            f[d][0][q] = c[q] + h;
+            f[d][1][q] = c[q] - h;
+        }
+    double mu[3][2], p[3][2];
+    for (int d = 0; d < 3; ++d)
+        for (int s = 0; s < 2; ++s) {
+            mu[d][s] = mu_of(k, f[d][s][F3_T]);
+            p[d][s] = (k.R * f[d][s][F3_T]) * f[d][s][F3_RHO];
+        }
+    const double muC = mu_of(k, c[F3_T]);
+
+    double F, l;
+    // ---- continuity
+    F = c[F3_RHO];
+    o.aU[E3_RHO] = unknown_coeff(F, c[F3_RHO]) * k.vol;
+    l = 0.0 + (-F) * k.vol;
+    for (int d = 0; d < 3; ++d) {
+        l = l + ((f[d][0][F3_RHO] * f[d][0][F3_U + d]) * A[d]) * dt;
+        l = l - ((f[d][1][F3_RHO] * f[d][1][F3_U + d]) * A[d]) * dt;
+    }
+    o.lhs[E3_RHO] = l;
+    // ---- momentum, component cc (equation slot E3_U + cc)
+    for (int cc = 0; cc < 3; ++cc) {
+        F = c[F3_RHO] * c[F3_U + cc];
+        o.aU[E3_U + cc] = unknown_coeff(F, c[F3_U + cc]) * k.vol;
+        l = 0.0 + (-F) * k.vol;
+        for (int d = 0; d < 3; ++d) {
+            l = l + (((f[d][0][F3_RHO] * f[d][0][F3_U + cc]) * f[d][0][F3_U + d]) * A[d]) * dt;
+            l = l - (((f[d][1][F3_RHO] * f[d][1][F3_U + cc]) * f[d][1][F3_U + d]) * A[d]) * dt;
+        }
+        l = l + (p[cc][0] * A[cc]) * dt;
+        l = l - (p[cc][1] * A[cc]) * dt;
+        o.lhs[E3_U + cc] = l;
+    }
+    // ---- energy
+    F = (c[F3_RHO] * c[F3_T]) * k.cv;
+    o.aU[E3_T] = unknown_coeff(F, c[F3_T]) * k.vol;
+    l = 0.0 + (-F) * k.vol;
+    for (int d = 0; d < 3; ++d) {
+        l = l + ((((f[d][0][F3_RHO] * f[d][0][F3_T]) * f[d][0][F3_U + d]) * k.cv) * A[d]) * dt;
+        l = l - ((((f[d][1][F3_RHO] * f[d][1][F3_T]) * f[d][1][F3_U + d]) * k.cv) * A[d]) * dt;
+    }
+    for (int d = 0; d < 3; ++d) {
+        l = l + ((p[d][0] * f[d][0][F3_U + d]) * A[d]) * dt;
+        l = l - ((p[d][1] * f[d][1][F3_U + d]) * A[d]) * dt;
+    }
+    o.lhs[E3_T] = l;
+    // ---- dye
+    F = c[F3_RHO] * c[F3_DYE];
+    o.aU[E3_DYE] = unknown_coeff(F, c[F3_DYE]) * k.vol;
+    l = 0.0 + (-F) * k.vol;
+    for (int d = 0; d < 3; ++d) {
+        l = l + (((f[d][0][F3_RHO] * f[d][0][F3_DYE]) * f[d][0][F3_U + d]) * A[d]) * dt;
+        l = l - (((f[d][1][F3_RHO] * f[d][1][F3_DYE]) * f[d][1][F3_U + d]) * A[d]) * dt;
+    }
+    o.lhs[E3_DYE] = l;
+
+    // ---- centre products, scaled per direction
+    double a[3], a2[3];
+    for (int cc = 0; cc < 3; ++cc) {
+        a[cc] = muC * c[F3_U + cc];
+        a2[cc] = (a[cc] * muC) * c[F3_U + cc];
+    }
+    const double g = muC * c[F3_DYE];
+    const double tk = c[F3_T] * k.k, gd = g * k.dyef;
+    SameDir3* S[3] = {&o.sx.s, &o.sy.s, &o.sz.s};
+    for (int d = 0; d < 3; ++d) {
+        SameDir3& s = *S[d];
+        for (int cc = 0; cc < 3; ++cc) {
+            s.m[cc] = (a[cc] * A[d]) * dt;
+            s.sqh[cc] = ((a2[cc] * 0.5) * A[d]) * dt;
+        }
+        s.m23 = ((a[d] * k.m23) * A[d]) * dt;
+        s.t = (tk * A[d]) * dt;
+        s.sq83 = ((a2[d] * k.c83h) * A[d]) * dt;
+        s.m83 = ((a[d] * k.c83n) * A[d]) * dt;
+        s.g = (gd * A[d]) * dt;
+    }
+    // ---- face products: mf[d][s][cc] = mu_f * (u_cc)_f on face (d, s)
+    double mf[3][2][3];
+    for (int d = 0; d < 3; ++d)
+        for (int s = 0; s < 2; ++s)
+            for (int cc = 0; cc < 3; ++cc) mf[d][s][cc] = mu[d][s] * f[d][s][F3_U + cc];
+    const double Ax = A[0], Ay = A[1], Az = A[2];
+    for (int s = 0; s < 2; ++s) {
+        // consumed by the +-X neighbours
+        o.sx.yMuV[s] = (mf[1][s][1] * Ay) * dt;
+        o.sx.yMuU23[s] = ((mf[1][s][0] * k.m23) * Ay) * dt;
+        o.sx.yMuUV[s] = ((mf[1][s][0] * f[1][s][F3_V]) * Ay) * dt;
+        o.sx.yMuU[s] = (mf[1][s][0] * Ay) * dt;
+        o.sx.yV[s] = (f[1][s][F3_V] * Ay) * dt;
+        o.sx.zMuW[s] = (mf[2][s][2] * Az) * dt;
+        o.sx.zMuU23[s] = ((mf[2][s][0] * k.m23) * Az) * dt;
+        o.sx.zMuUW[s] = ((mf[2][s][0] * f[2][s][F3_W]) * Az) * dt;
+        o.sx.zMuU[s] = (mf[2][s][0] * Az) * dt;
+        o.sx.zW[s] = (f[2][s][F3_W] * Az) * dt;
+        // consumed by the +-Y neighbours
+        o.sy.xMuV23[s] = ((mf[0][s][1] * k.m23) * Ax) * dt;
+        o.sy.xMuU[s] = (mf[0][s][0] * Ax) * dt;
+        o.sy.zMuW[s] = (mf[2][s][2] * Az) * dt;
+        o.sy.zMuV23[s] = ((mf[2][s][1] * k.m23) * Az) * dt;
+        // consumed by the +-Z neighbours
+        o.sz.xMuW23[s] = ((mf[0][s][2] * k.m23) * Ax) * dt;
+        o.sz.xMuU[s] = (mf[0][s][0] * Ax) * dt;
+        o.sz.yMuW23[s] = ((mf[1][s][2] * k.m23) * Ay) * dt;
+        o.sz.yMuV[s] = (mf[1][s][1] * Ay) * dt;
+        o.sz.yMuWV[s] = ((mf[1][s][2] * f[1][s][F3_V]) * Ay) * dt;
+        o.sz.yMuW[s] = (mf[1][s][2] * Ay) * dt;
+        o.sz.yV[s] = (f[1][s][F3_V] * Ay) * dt;
+    }
+}
+
+// Right-hand sides and solve.  XP/XM, YP/YM, ZP/ZM: shares of the +/- neighbours in x, y, z (a
+// clamped neighbour is the cell itself).  out[] in E3_* order.
+CFD_HD void phaseB3(const SweepConsts& k, const PhaseA3& C, const ShareX3& XP, const ShareX3& XM,
+                    const ShareY3& YP, const ShareY3& YM, const ShareZ3& ZP, const ShareZ3& ZM, double out[NE3]) {
+    const double hx = k.hx, hy = k.hy, hz = k.hz, Hx = k.Hx, Hy = k.Hy, Hz = k.Hz;
+    const SameDir3 &cx = C.sx.s, &cy = C.sy.s, &cz = C.sz.s;
+    const SameDir3 &xp = XP.s, &xm = XM.s, &yp = YP.s, &ym = YM.s, &zp = ZP.s, &zm = ZM.s;
+    double r;
+#define SAME(r, up, lo, cc, h)   do { (r) = (r) + ((up) - (cc)) / (h); (r) = (r) + ((lo) - (cc)) / (h); } while (0)
+#define SAMEN(r, up, lo, cc, h)  do { (r) = (r) + ((cc) - (up)) / (h); (r) = (r) + ((cc) - (lo)) / (h); } while (0)
+#define CROSS(r, n1, n2, fld, H)  do { (r) = (r) + ((n1).fld[0] - (n2).fld[0]) / (H); (r) = (r) + ((n2).fld[1] - (n1).fld[1]) / (H); } while (0)
+#define CROSSN(r, n1, n2, fld, H) do { (r) = (r) + ((n2).fld[0] - (n1).fld[0]) / (H); (r) = (r) + ((n1).fld[1] - (n2).fld[1]) / (H); } while (0)
+    // ---- continuity
+    r = 0.0 + 0.0;
+    out[E3_RHO] = (r - C.lhs[E3_RHO]) / C.aU[E3_RHO];
+    // ---- U momentum
+    r = 0.0;
+    SAME(r, xp.m[0], xm.m[0], cx.m[0], hx);
+    SAME(r, yp.m[0], ym.m[0], cy.m[0], hy);
+    SAME(r, zp.m[0], zm.m[0], cz.m[0], hz);
+    SAME(r, xp.m[0], xm.m[0], cx.m[0], hx);
+    CROSS(r, XP, XM, yMuV, Hx);
+    CROSS(r, XP, XM, zMuW, Hx);
+    SAME(r, xp.m23, xm.m23, cx.m23, hx);
+    CROSS(r, YP, YM, xMuV23, Hy);
+    CROSS(r, ZP, ZM, xMuW23, Hz);
+    out[E3_U] = (r - C.lhs[E3_U]) / C.aU[E3_U];
+    // ---- V momentum
+    r = 0.0;
+    SAME(r, xp.m[1], xm.m[1], cx.m[1], hx);
+    SAME(r, yp.m[1], ym.m[1], cy.m[1], hy);
+    SAME(r, zp.m[1], zm.m[1], cz.m[1], hz);
+    CROSS(r, YP, YM, xMuU, Hy);
+    SAME(r, yp.m[1], ym.m[1], cy.m[1], hy);
+    CROSS(r, YP, YM, zMuW, Hy);
+    CROSS(r, XP, XM, yMuU23, Hx);
+    SAME(r, yp.m23, ym.m23, cy.m23, hy);
+    CROSS(r, ZP, ZM, yMuW23, Hz);
+    out[E3_V] = (r - C.lhs[E3_V]) / C.aU[E3_V];
+    // ---- W momentum
+    r = 0.0;
+    SAME(r, xp.m[2], xm.m[2], cx.m[2], hx);
+    SAME(r, yp.m[2], ym.m[2], cy.m[2], hy);
+    SAME(r, zp.m[2], zm.m[2], cz.m[2], hz);
+    CROSS(r, ZP, ZM, xMuU, Hz);
+    CROSS(r, ZP, ZM, yMuV, Hz);
+    SAME(r, zp.m[2], zm.m[2], cz.m[2], hz);
+    CROSS(r, XP, XM, zMuU23, Hx);
+    CROSS(r, YP, YM, zMuV23, Hy);
+    SAME(r, zp.m23, zm.m23, cz.m23, hz);
+    out[E3_W] = (r - C.lhs[E3_W]) / C.aU[E3_W];
+    // ---- energy
+    r = 0.0;
+    SAME(r, xp.t, xm.t, cx.t, hx);
+    SAME(r, yp.t, ym.t, cy.t, hy);
+    SAME(r, zp.t, zm.t, cz.t, hz);
+    SAME(r, xp.sq83, xm.sq83, cx.sq83, hx);   SAME(r, xp.m83, xm.m83, cx.m83, hx);      // [Mew,U] 8/3 X
+    SAME(r, yp.sq83, ym.sq83, cy.sq83, hy);   SAME(r, yp.m83, ym.m83, cy.m83, hy);      // [Mew,V] 8/3 Y
+    SAME(r, zp.sq83, zm.sq83, cz.sq83, hz);   SAME(r, zp.m83, zm.m83, cz.m83, hz);      // [Mew,W] 8/3 Z
+    SAME(r, yp.sqh[0], ym.sqh[0], cy.sqh[0], hy);  SAMEN(r, yp.m[0], ym.m[0], cy.m[0], hy);   // [Mew,U] 1 Y
+    SAME(r, xp.sqh[1], xm.sqh[1], cx.sqh[1], hx);  SAMEN(r, xp.m[1], xm.m[1], cx.m[1], hx);   // [Mew,V] 1 X
+    SAME(r, zp.sqh[0], zm.sqh[0], cz.sqh[0], hz);  SAMEN(r, zp.m[0], zm.m[0], cz.m[0], hz);   // [Mew,U] 1 Z
+    SAME(r, xp.sqh[2], xm.sqh[2], cx.sqh[2], hx);  SAMEN(r, xp.m[2], xm.m[2], cx.m[2], hx);   // [Mew,W] 1 X
+    SAME(r, zp.sqh[1], zm.sqh[1], cz.sqh[1], hz);  SAMEN(r, zp.m[1], zm.m[1], cz.m[1], hz);   // [Mew,V] 1 Z
+    SAME(r, yp.sqh[2], ym.sqh[2], cy.sqh[2], hy);  SAMEN(r, yp.m[2], ym.m[2], cy.m[2], hy);   // [Mew,W] 1 Y
+    CROSS(r, XP, XM, yMuUV, Hx);  CROSSN(r, XP, XM, yMuU, Hx);  CROSSN(r, XP, XM, yV, Hx);    // [Mew,U][V] X Y
+    CROSS(r, XP, XM, zMuUW, Hx);  CROSSN(r, XP, XM, zMuU, Hx);  CROSSN(r, XP, XM, zW, Hx);    // [Mew,U][W] X Z
+    CROSS(r, ZP, ZM, yMuWV, Hz);  CROSSN(r, ZP, ZM, yMuW, Hz);  CROSSN(r, ZP, ZM, yV, Hz);    // [Mew,W][V] Z Y
+    out[E3_T] = (r - C.lhs[E3_T]) / C.aU[E3_T];
+    // ---- dye
+    r = 0.0;
+    SAME(r, xp.g, xm.g, cx.g, hx);
+    SAME(r, yp.g, ym.g, cy.g, hy);
+    SAME(r, zp.g, zm.g, cz.g, hz);
+    out[E3_DYE] = (r - C.lhs[E3_DYE]) / C.aU[E3_DYE];
+#undef SAME
+#undef SAMEN
+#undef CROSS
+#undef CROSSN
+}
+
 }  // namespace cfd

@@ -182,6 +182,79 @@ def test_virtual_rank_slabs_match_single_domain(world, shape):
     assert abs(total - ref.total_density()) <= 1e-12 * abs(total)
 
 
+@pytest.mark.parametrize("shape,seed,zero_v,flags", [((7, 6, 5), 1, False, 0), ((3, 3, 3), 2, True, 0),
+                                                      ((12, 9, 1), 3, False, 2), ((4, 1, 70), 4, False, 0),
+                                                      ((1, 1, 1), 5, False, 2), ((9, 20, 13), 6, True, 0),
+                                                      ((20, 3, 1), 7, False, 0)])
+def test_sweeps_bit_exact_3d(shape, seed, zero_v, flags):
+    """General 3-D kernel (also reached with nz == 1 when W != 0 or when forced): bit-exact against
+    Oracle B over sweeps and full steps."""
+    params, fields, active = small_case(shape[0], shape[1], shape[2], seed, zero_v)
+    if shape == (20, 3, 1):
+        fields[2][:] = np.random.default_rng(1).uniform(-0.2, 0.2, fields[2].size)   # nz == 1 with W != 0
+    g = _gpu_graph(params, fields, active, flags)
+    b = _oracle(params, fields, active, pow_mode=1)
+    assert g.live_fields == 6 and g.kernel_name() == "sweep3d_simple"
+    for i, st in enumerate([True, False, False]):
+        g.sweep(st)
+        b.sweep(st)
+        _assert_slots_bit_equal(g, b, "sweep %d" % i)
+    g.time_filter(); b.time_filter()
+    for step in range(2):
+        g.step(1)
+        b.step(1)
+        _assert_slots_bit_equal(g, b, "step %d" % step)
+        td, tb = g.total_density(), b.total_density()
+        assert abs(td - tb) <= 1e-12 * abs(tb)
+
+
+@pytest.mark.parametrize("name", ["case_7x6x5", "case_3x3x3_zero_vw"])
+def test_golden_fixtures_3d_through_c_abi(name):
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    params = json.loads(str(z["params"]))
+    params.update(device=-1, flags=0, ghost_lo=0, ghost_hi=0)
+    fields = [z["in_%d" % k] for k in range(7)]
+    for i, st in enumerate(z["sweep_flags"]):
+        g = _gpu_graph(params, fields, z["active"], 0)
+        g.sweep(bool(st))
+        fg = g.read_fields(0)
+        for k in range(7):
+            assert rel_err(fg[k], z["sweep%d_%d" % (i, k)]) <= 1e-13, (name, i, PROPS[k])
+        fields = [z["sweep%d_%d" % (i, k)] for k in range(7)]
+
+
+def test_virtual_rank_slabs_3d():
+    import torch
+    from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
+    nx, ny, nz, world = 10, 7, 6, 3
+    params, fields, active = small_case(nx, ny, nz, seed=41)
+    ref = _gpu_graph(params, fields, active, 0)
+    ref.step(2)
+    peers = []
+    for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, nx, ny * nz, world)):
+        p = dict(params)
+        p["nx"] = x1 - x0
+        peers.append(SlabGraph(p, f, a, rank=r, world=world, comm=LocalComm(r, peers)))
+    bounds = [nx * r // world for r in range(world + 1)]
+    for _ in range(2):
+        for st in (True, False, False):
+            for g in peers:
+                g.exchange()
+            torch.cuda.synchronize()
+            for g in peers:
+                g.backend.sweep(st)
+        for g in peers:
+            g.time_filter()
+    pl = ny * nz
+    for r, g in enumerate(peers):
+        for rel in range(3):
+            got, want = g.read_fields(rel), ref.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(got[k], want[k][bounds[r] * pl:bounds[r + 1] * pl]), (r, rel, PROPS[k])
+
+
 def test_error_paths():
     from cfd_amd import _capi
     from cfd_amd.solver import AdjGraph

@@ -47,3 +47,25 @@ def test_sweep2d_math_bit_exact(hm, shape, seed, zero_v):
             assert bits_equal(out[j], fb[i]), (sweep, i)
         assert np.all(fb[2] == 0)
         cur = out
+
+
+@pytest.mark.parametrize("shape,seed,zero_v", [((7, 6, 5), 1, False), ((3, 3, 3), 2, True), ((12, 9, 1), 3, False),
+                                                ((4, 1, 6), 4, False), ((1, 1, 1), 5, False), ((9, 8, 2), 6, True)])
+def test_sweep3d_math_bit_exact(hm, shape, seed, zero_v):
+    nx, ny, nz = shape
+    params, fields, active = small_case(nx, ny, nz, seed, zero_v)
+    p = oracle_params(params)
+    b = OracleB(p, fields, active, pow_mode=1)
+    live = (0, 1, 2, 3, 4, 6)
+    cur = [fields[i].copy() for i in live]
+    d = ctypes.c_double
+    for sweep in range(4):
+        b.sweep(sweep == 0)
+        out = [np.empty(nx * ny * nz) for _ in range(6)]
+        hm.hm_sweep3d(nx, ny, nz, d(p["dx"]), d(p["dy"]), d(p["dz"]), d(p["dt"]), d(p["lambda_"]), d(p["suth"]),
+                      d(p["R"]), d(p["cv"]), d(p["k"]), d(p["dye_f"]), _ptrs(cur),
+                      active.ctypes.data_as(ctypes.c_void_p), _ptrs(out))
+        fb = b.read_fields(0)
+        for j, i in enumerate(live):
+            assert bits_equal(out[j], fb[i]), (sweep, i, float(np.max(np.abs(out[j] - fb[i]))))
+        cur = out
