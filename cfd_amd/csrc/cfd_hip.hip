@@ -66,6 +66,7 @@ struct cfd_handle {
     int device;
     int cmt, cat;
     SweepConsts K;
+    FastConsts KF;
     int chunk;              // x-planes per block of the tiled sweep
     int variant;            // tiled-kernel launch shape (tuning knob)
     // sweep timing
@@ -89,9 +90,56 @@ static inline double* slot_base(const cfd_handle* h, int t) {
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-// One thread per cell; every thread evaluates phase A for its cell and again for its four face
-// neighbours.  Redundant by design: this is the plain reading of the update, kept as the
-// on-device cross-check of the tiled kernel.
+// Arithmetic policies for the 2-D kernels: the strict (reference operation order) and the fast
+// (re-associated) form of phase A / phase B share all of the kernel plumbing below.
+struct MathStrict2 {
+    using Consts = SweepConsts;
+    using PA = PhaseA2;
+    using SX = ShareX2;
+    using SY = ShareY2;
+    static constexpr int NSY = 12;
+    __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* e, const double* w,
+                                                  const double* n, const double* s, PA& o) {
+        phaseA2(K, c, e, w, n, s, o);
+    }
+    __device__ __forceinline__ static void phaseB(const Consts& K, const PA& C, const SX& XE, const SX& XW,
+                                                  const SY& YN, const SY& YS, double* o) {
+        phaseB2(K, C, XE, XW, YN, YS, o);
+    }
+    __device__ __forceinline__ static void put_sy(double* __restrict__ l, int st, const SY& s) {
+        l[0 * st] = s.aY;    l[1 * st] = s.bY;    l[2 * st] = s.bY23;  l[3 * st] = s.tY;
+        l[4 * st] = s.b2Y83; l[5 * st] = s.bY83;  l[6 * st] = s.a2Yh;  l[7 * st] = s.gY;
+        l[8 * st] = s.bE23;  l[9 * st] = s.bW23;  l[10 * st] = s.aE;   l[11 * st] = s.aW;
+    }
+    __device__ __forceinline__ static void get_sy(const double* __restrict__ l, int st, SY& s) {
+        s.aY = l[0 * st];    s.bY = l[1 * st];    s.bY23 = l[2 * st];  s.tY = l[3 * st];
+        s.b2Y83 = l[4 * st]; s.bY83 = l[5 * st];  s.a2Yh = l[6 * st];  s.gY = l[7 * st];
+        s.bE23 = l[8 * st];  s.bW23 = l[9 * st];  s.aE = l[10 * st];   s.aW = l[11 * st];
+    }
+};
+
+struct MathFast2 {
+    using Consts = FastConsts;
+    using PA = PhaseAF;
+    using SX = ShareXF;
+    using SY = ShareYF;
+    static constexpr int NSY = 6;
+    __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* e, const double* w,
+                                                  const double* n, const double* s, PA& o) {
+        phaseA2f(K, c, e, w, n, s, o);
+    }
+    __device__ __forceinline__ static void phaseB(const Consts& K, const PA& C, const SX& XE, const SX& XW,
+                                                  const SY& YN, const SY& YS, double* o) {
+        phaseB2f(K, C, XE, XW, YN, YS, o);
+    }
+    __device__ __forceinline__ static void put_sy(double* __restrict__ l, int st, const SY& s) {
+        l[0 * st] = s.a;  l[1 * st] = s.b;  l[2 * st] = s.g;  l[3 * st] = s.py;  l[4 * st] = s.deb;  l[5 * st] = s.dea;
+    }
+    __device__ __forceinline__ static void get_sy(const double* __restrict__ l, int st, SY& s) {
+        s.a = l[0 * st];  s.b = l[1 * st];  s.g = l[2 * st];  s.py = l[3 * st];  s.deb = l[4 * st];  s.dea = l[5 * st];
+    }
+};
+
 __device__ __forceinline__ void load5(const double* __restrict__ src, long plane5, int ny, int x, int y,
                                       double v[NF2]) {
     const double* p = src + (long)x * plane5 + y;
@@ -99,38 +147,9 @@ __device__ __forceinline__ void load5(const double* __restrict__ src, long plane
     for (int f = 0; f < NF2; ++f) v[f] = p[(long)f * ny];
 }
 
-__device__ __forceinline__ void phaseA2_at(const SweepConsts& K, const double* __restrict__ src, long plane5,
-                                           int ny, int x, int y, int xlo, int xhi, PhaseA2& o) {
-    const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
-    const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
-    double c[NF2], e[NF2], w[NF2], n[NF2], s[NF2];
-    load5(src, plane5, ny, x, y, c);
-    load5(src, plane5, ny, xe, y, e);
-    load5(src, plane5, ny, xw, y, w);
-    load5(src, plane5, ny, x, yn, n);
-    load5(src, plane5, ny, x, ys, s);
-    phaseA2(K, c, e, w, n, s, o);
-}
-
-__global__ void __launch_bounds__(64)
-sweep2d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict__ dst,
-               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi) {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    const int x = blockIdx.y;
-    if (y >= ny || x >= nx) return;
-    const long plane5 = (long)NF2 * ny;
-    const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
-    const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
-    PhaseA2 C, T;
-    ShareX2 XE, XW;
-    ShareY2 YN, YS;
-    phaseA2_at(K, src, plane5, ny, x, y, xlo, xhi, C);
-    phaseA2_at(K, src, plane5, ny, xe, y, xlo, xhi, T);  XE = T.sx;
-    phaseA2_at(K, src, plane5, ny, xw, y, xlo, xhi, T);  XW = T.sx;
-    phaseA2_at(K, src, plane5, ny, x, yn, xlo, xhi, T);  YN = T.sy;
-    phaseA2_at(K, src, plane5, ny, x, ys, xlo, xhi, T);  YS = T.sy;
-    double o[5];
-    phaseB2(K, C, XE, XW, YN, YS, o);
+__device__ __forceinline__ void store5(const double* __restrict__ src, double* __restrict__ dst,
+                                       const uint8_t* __restrict__ active, long plane5, int ny, int x, int y,
+                                       const double o[5]) {
     const bool act = active[(long)x * ny + y] != 0;
     const double* sp = src + (long)x * plane5 + y;
     double* dp = dst + (long)x * plane5 + y;
@@ -139,6 +158,46 @@ sweep2d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict
     dp[(long)F2_U * ny] = act ? o[E2_U] : sp[(long)F2_U * ny];
     dp[(long)F2_V * ny] = act ? o[E2_V] : sp[(long)F2_V * ny];
     dp[(long)F2_DYE * ny] = act ? o[E2_DYE] : sp[(long)F2_DYE * ny];
+}
+
+// One thread per cell; every thread evaluates phase A for its cell and again for its four face
+// neighbours.  Redundant by design: this is the plain reading of the update, kept as the
+// on-device cross-check of the tiled kernel.
+template <class M>
+__device__ __forceinline__ void phaseA2_at(const typename M::Consts& K, const double* __restrict__ src, long plane5,
+                                           int ny, int x, int y, int xlo, int xhi, typename M::PA& o) {
+    const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
+    const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
+    double c[NF2], e[NF2], w[NF2], n[NF2], s[NF2];
+    load5(src, plane5, ny, x, y, c);
+    load5(src, plane5, ny, xe, y, e);
+    load5(src, plane5, ny, xw, y, w);
+    load5(src, plane5, ny, x, yn, n);
+    load5(src, plane5, ny, x, ys, s);
+    M::phaseA(K, c, e, w, n, s, o);
+}
+
+template <class M>
+__global__ void __launch_bounds__(64)
+sweep2d_simple(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
+               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.y;
+    if (y >= ny || x >= nx) return;
+    const long plane5 = (long)NF2 * ny;
+    const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
+    const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
+    typename M::PA C, T;
+    typename M::SX XE, XW;
+    typename M::SY YN, YS;
+    phaseA2_at<M>(K, src, plane5, ny, x, y, xlo, xhi, C);
+    phaseA2_at<M>(K, src, plane5, ny, xe, y, xlo, xhi, T);  XE = T.sx;
+    phaseA2_at<M>(K, src, plane5, ny, xw, y, xlo, xhi, T);  XW = T.sx;
+    phaseA2_at<M>(K, src, plane5, ny, x, yn, xlo, xhi, T);  YN = T.sy;
+    phaseA2_at<M>(K, src, plane5, ny, x, ys, xlo, xhi, T);  YS = T.sy;
+    double o[5];
+    M::phaseB(K, C, XE, XW, YN, YS, o);
+    store5(src, dst, active, plane5, ny, x, y, o);
 }
 
 // General 3-D sweep, one thread per cell (lanes along z, then y).  Each thread evaluates phase A
@@ -208,25 +267,11 @@ sweep3d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict
 //                 phase B of row j-1 (centre = row j-1, East = row j, West = row j-2,
 //                                     North/South = lds[(j-1)&1] of lanes t+1 / t-1)
 //                 one barrier
-constexpr int kShareY = 12;
-
-__device__ __forceinline__ void put_sy(double* __restrict__ l, int stride, const ShareY2& s) {
-    l[0 * stride] = s.aY;    l[1 * stride] = s.bY;    l[2 * stride] = s.bY23;  l[3 * stride] = s.tY;
-    l[4 * stride] = s.b2Y83; l[5 * stride] = s.bY83;  l[6 * stride] = s.a2Yh;  l[7 * stride] = s.gY;
-    l[8 * stride] = s.bE23;  l[9 * stride] = s.bW23;  l[10 * stride] = s.aE;   l[11 * stride] = s.aW;
-}
-
-__device__ __forceinline__ void get_sy(const double* __restrict__ l, int stride, ShareY2& s) {
-    s.aY = l[0 * stride];    s.bY = l[1 * stride];    s.bY23 = l[2 * stride];  s.tY = l[3 * stride];
-    s.b2Y83 = l[4 * stride]; s.bY83 = l[5 * stride];  s.a2Yh = l[6 * stride];  s.gY = l[7 * stride];
-    s.bE23 = l[8 * stride];  s.bW23 = l[9 * stride];  s.aE = l[10 * stride];   s.aW = l[11 * stride];
-}
-
-template <int NT, int MINW, bool PREFETCH>
+template <class M, int NT, int MINW, bool PREFETCH>
 __global__ void __launch_bounds__(NT, MINW)
-sweep2d_march(SweepConsts K, const double* __restrict__ src, double* __restrict__ dst,
+sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch) {
-    __shared__ double lds[2][kShareY][NT];
+    __shared__ double lds[2][M::NSY][NT];
     const int t = threadIdx.x;
     const int y = (int)blockIdx.x * (NT - 2) - 1 + t;
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
@@ -246,58 +291,48 @@ sweep2d_march(SweepConsts K, const double* __restrict__ src, double* __restrict_
     load5(src, plane5, ny, j0, yn, rn);
     load5(src, plane5, ny, j0, ys, rs);
 
-    PhaseA2 Ac;      // phase A of row j-1
-    ShareX2 Xw;      // x-products of row j-2
+    typename M::PA Ac;      // phase A of row j-1
+    typename M::SX Xw;      // x-products of row j-2
 
-    auto emit = [&](int x, const ShareX2& XE) {
+    auto emit = [&](int x, const typename M::SX& XE) {
         // phase B of row x; Ac holds its phase A, lds[x&1] its neighbours' y-products
-        ShareY2 YN, YS;
+        typename M::SY YN, YS;
         const int tn = t + 1 > NT - 1 ? NT - 1 : t + 1, tsn = t - 1 < 0 ? 0 : t - 1;
-        get_sy(&lds[x & 1][0][tn], NT, YN);
-        get_sy(&lds[x & 1][0][tsn], NT, YS);
-        ShareX2 XW = Xw;
-        if (x - 1 < xlo) XW = Ac.sx;              // clamped West neighbour is the cell itself
+        M::get_sy(&lds[x & 1][0][tn], NT, YN);
+        M::get_sy(&lds[x & 1][0][tsn], NT, YS);
         double o[5];
-        phaseB2(K, Ac, XE, XW, YN, YS, o);
-        if (writer) {
-            const bool act = active[(long)x * ny + y] != 0;
-            const double* sp = src + (long)x * plane5 + y;
-            double* dp = dst + (long)x * plane5 + y;
-            dp[(long)F2_RHO * ny] = o[E2_RHO];
-            dp[(long)F2_T * ny] = o[E2_T];
-            dp[(long)F2_U * ny] = act ? o[E2_U] : sp[(long)F2_U * ny];
-            dp[(long)F2_V * ny] = act ? o[E2_V] : sp[(long)F2_V * ny];
-            dp[(long)F2_DYE * ny] = act ? o[E2_DYE] : sp[(long)F2_DYE * ny];
-        }
+        M::phaseB(K, Ac, XE, Xw, YN, YS, o);
+        if (writer) store5(src, dst, active, plane5, ny, x, y, o);
+    };
+    auto advance = [&](int j) {
+        // shift the raw-value window one row: (rw, rc, re) <- rows (j, j+1, j+2); N/S of row j+1
+        const int jn = clampx(j + 1);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { rw[f] = rc[f]; rc[f] = re[f]; }
+        load5(src, plane5, ny, clampx(j + 2), cy, re);
+        load5(src, plane5, ny, jn, yn, rn);
+        load5(src, plane5, ny, jn, ys, rs);
     };
 
-    for (int j = j0; j <= j1; ++j) {
-        // prefetch the raw values the next iteration needs
-        double re2[NF2], rn2[NF2], rs2[NF2];
-        const int jn = clampx(j + 1);
-        if (PREFETCH) {
-            load5(src, plane5, ny, clampx(j + 2), cy, re2);
-            load5(src, plane5, ny, jn, yn, rn2);
-            load5(src, plane5, ny, jn, ys, rs2);
-        }
+    // first row: nothing to emit yet.  Its x-products also stand in for the row before it, which
+    // is exactly the clamp-to-self rule when that row lies outside the domain, and is replaced
+    // before use otherwise.
+    M::phaseA(K, rc, re, rw, rn, rs, Ac);
+    M::put_sy(&lds[j0 & 1][0][t], NT, Ac.sy);
+    Xw = Ac.sx;
+    advance(j0);
+    __syncthreads();
 
-        PhaseA2 An;
-        phaseA2(K, rc, re, rw, rn, rs, An);
-        put_sy(&lds[j & 1][0][t], NT, An.sy);
+    for (int j = j0 + 1; j <= j1; ++j) {
+        typename M::PA An;
+        M::phaseA(K, rc, re, rw, rn, rs, An);
+        M::put_sy(&lds[j & 1][0][t], NT, An.sy);
+        advance(j);
         const int x = j - 1;
         if (x >= xs) emit(x, An.sx);               // block-uniform
         __syncthreads();
         Xw = Ac.sx;
         Ac = An;
-        if (!PREFETCH) {
-            load5(src, plane5, ny, clampx(j + 2), cy, re2);
-            load5(src, plane5, ny, jn, yn, rn2);
-            load5(src, plane5, ny, jn, ys, rs2);
-        }
-#pragma unroll
-        for (int f = 0; f < NF2; ++f) {
-            rw[f] = rc[f]; rc[f] = re[f]; re[f] = re2[f]; rn[f] = rn2[f]; rs[f] = rs2[f];
-        }
     }
     // last owned row of the domain: its clamped East neighbour is the cell itself
     if (j1 < xe) emit(xe - 1, Ac.sx);
@@ -375,33 +410,49 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
         }
         HIP_TRY(hipEventRecord(ev.a, h->stream));
     }
+    const bool fast = (p.flags & CFD_FLAG_FAST_MATH) != 0;
+    const uint8_t* act = h->d_active + h->plane;
     if (h->two_d && (p.flags & CFD_FLAG_SIMPLE_KERNEL)) {
         dim3 block(64), grid((p.ny + 63) / 64, p.nx);
-        hipLaunchKernelGGL(sweep2d_simple, grid, block, 0, h->stream, h->K, src, dst,
-                           h->d_active + h->plane, p.nx, p.ny, xlo, xhi);
+        if (fast)
+            hipLaunchKernelGGL(sweep2d_simple<MathFast2>, grid, block, 0, h->stream, h->KF, src, dst, act, p.nx,
+                               p.ny, xlo, xhi);
+        else
+            hipLaunchKernelGGL(sweep2d_simple<MathStrict2>, grid, block, 0, h->stream, h->K, src, dst, act, p.nx,
+                               p.ny, xlo, xhi);
     } else if (h->two_d) {
         const int ch = h->chunk;
-#define LAUNCH_MARCH(NT, MINW, PF)                                                                 \
+#define LAUNCH_MARCH(M, KK, NT, MINW, PF)                                                          \
     do {                                                                                           \
         dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (p.nx + ch - 1) / ch);                    \
-        hipLaunchKernelGGL((sweep2d_march<NT, MINW, PF>), grid, block, 0, h->stream, h->K, src,    \
-                           dst, h->d_active + h->plane, p.nx, p.ny, xlo, xhi, ch);                 \
+        hipLaunchKernelGGL((sweep2d_march<M, NT, MINW, PF>), grid, block, 0, h->stream, KK, src,   \
+                           dst, act, p.nx, p.ny, xlo, xhi, ch);                                    \
     } while (0)
-        switch (h->variant) {
-            case 1: LAUNCH_MARCH(256, 2, true); break;
-            case 2: LAUNCH_MARCH(256, 2, false); break;
-            case 3: LAUNCH_MARCH(128, 1, true); break;
-            case 4: LAUNCH_MARCH(128, 1, false); break;
-            case 5: LAUNCH_MARCH(64, 1, true); break;
-            case 6: LAUNCH_MARCH(64, 1, false); break;
-            case 7: LAUNCH_MARCH(256, 1, false); break;
-            default: LAUNCH_MARCH(256, 1, true); break;
+        if (fast) {
+            switch (h->variant) {
+                case 1: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, true); break;
+                case 2: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, false); break;
+                case 3: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, true); break;
+                case 4: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, false); break;
+                case 5: LAUNCH_MARCH(MathFast2, h->KF, 256, 4, false); break;
+                case 6: LAUNCH_MARCH(MathFast2, h->KF, 128, 4, false); break;
+                case 7: LAUNCH_MARCH(MathFast2, h->KF, 256, 3, false); break;
+                default: LAUNCH_MARCH(MathFast2, h->KF, 256, 1, true); break;
+            }
+        } else {
+            switch (h->variant) {
+                case 1: LAUNCH_MARCH(MathStrict2, h->K, 256, 2, true); break;
+                case 3: LAUNCH_MARCH(MathStrict2, h->K, 128, 1, true); break;
+                case 4: LAUNCH_MARCH(MathStrict2, h->K, 128, 1, false); break;
+                case 0: LAUNCH_MARCH(MathStrict2, h->K, 256, 1, true); break;
+                default: LAUNCH_MARCH(MathStrict2, h->K, 256, 2, false); break;
+            }
         }
 #undef LAUNCH_MARCH
     } else {
         dim3 block(64), grid((unsigned)((h->plane + 63) / 64), p.nx);
-        hipLaunchKernelGGL(sweep3d_simple, grid, block, 0, h->stream, h->K, src, dst,
-                           h->d_active + h->plane, p.nx, p.ny, p.nz, xlo, xhi);
+        hipLaunchKernelGGL(sweep3d_simple, grid, block, 0, h->stream, h->K, src, dst, act, p.nx, p.ny, p.nz, xlo,
+                           xhi);
     }
     HIP_TRY(hipGetLastError());
     if (h->timing) {
@@ -487,6 +538,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->nf = h->two_d ? 5 : 6;
     h->slot_elems = (size_t)h->nf * (p->nx + 2) * h->plane;
     h->K = make_consts(p->dx, p->dy, p->dz, p->dt, p->lambda, p->suth, p->R, p->cv, p->k, p->dye_f);
+    h->KF = make_fast_consts(h->K, p->dx, p->dy);
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
     if (const char* e = getenv("CFD_CHUNK")) { int v = atoi(e); if (v >= 1) h->chunk = v; }
@@ -662,7 +714,9 @@ int cfd_set_stream(cfd_handle* h, void* stream) {
 const char* cfd_kernel_name(cfd_handle* h) {
     if (!h) return "";
     if (!h->two_d) return "sweep3d_simple";
-    return (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) ? "sweep2d_simple" : "sweep2d_march";
+    const bool fast = (h->p.flags & CFD_FLAG_FAST_MATH) != 0;
+    if (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) return fast ? "sweep2d_simple<fast>" : "sweep2d_simple<strict>";
+    return fast ? "sweep2d_march<fast>" : "sweep2d_march<strict>";
 }
 
 int cfd_sync(cfd_handle* h) {

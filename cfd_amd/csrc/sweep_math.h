@@ -317,6 +317,164 @@ CFD_HD void phaseB2(const SweepConsts& k, const PhaseA2& C, const ShareX2& XE, c
 
 
 // ------------------------------------------------------------------------------------------
+// 2-D case, re-associated arithmetic ("fast").  Same equations, same limiter, same NaN -> 1 rule,
+// but each equation is solved in increment form
+//     phi_new = phi - (div(flux) - rhs/vol) / coefficient
+// with the geometric factors folded into per-direction constants, every second difference taken
+// once on a per-cell combination of products, divisions by the constant intervals replaced by
+// multiplications, and mu and 1/rho evaluated by Newton iterations on the hardware estimates.
+// Mathematically identical to the strict form; rounding differs at the level of the strict
+// form's own rounding noise (<= 1e-13 of the field scale per sweep).
+// ------------------------------------------------------------------------------------------
+struct FastConsts {
+    double rcx, rcy;        // dt/dx, dt/dy                  (flux divergence per unit volume)
+    double kxx, kyy, kxy;   // dt/dx^2, dt/dy^2, dt/(2 dx dy)
+    double kxxm, kyym;      // (2 + m23) * kxx, (2 + m23) * kyy
+    double kxym;            // m23 * kxy
+    double lambda, suth, R, cv, rcv, k, dyef;
+    double c83h, c83n;
+};
+
+inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy) {
+    FastConsts f;
+    f.rcx = c.dt / dx;  f.rcy = c.dt / dy;
+    f.kxx = c.dt / (dx * dx);  f.kyy = c.dt / (dy * dy);  f.kxy = c.dt / (2.0 * dx * dy);
+    f.kxxm = (2.0 + c.m23) * f.kxx;  f.kyym = (2.0 + c.m23) * f.kyy;  f.kxym = c.m23 * f.kxy;
+    f.lambda = c.lambda; f.suth = c.suth; f.R = c.R; f.cv = c.cv; f.rcv = 1.0 / c.cv; f.k = c.k; f.dyef = c.dyef;
+    f.c83h = c.c83h; f.c83n = c.c83n;
+    return f;
+}
+
+// 1/x and sqrt(x) to full double accuracy (not correctly rounded) from the hardware estimates.
+CFD_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+#else
+    return 1.0 / x;
+#endif
+}
+
+CFD_HD double fast_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    return fma(g, r, g);
+#else
+    return sqrt(x);
+#endif
+}
+
+CFD_HD double mu_fast(const FastConsts& k, double t) {
+    return (k.lambda * t) * (fast_sqrt(t) * fast_rcp(t + k.suth));
+}
+
+// What the East/West neighbours need from a cell.
+struct ShareXF {
+    double a, b, g;     // mu U, mu V, mu Dye at the centre
+    double px;          // k T + c83h a^2 + c83n a + b^2/2 - b
+    double q;           // N-minus-S difference of (mu_f U_f V_f - mu_f U_f - V_f)
+    double dnb, dna;    // N-minus-S difference of mu_f V_f, of mu_f U_f
+};
+// What the North/South neighbours need from a cell.
+struct ShareYF {
+    double a, b, g;
+    double py;          // k T + c83h b^2 + c83n b + a^2/2 - a
+    double deb, dea;    // E-minus-W difference of mu_f V_f, of mu_f U_f
+};
+struct PhaseAF {
+    double div[5];      // flux divergence per unit volume (E2_* order)
+    double phi[5];      // the cell's own rho, U, V, T, Dye
+    double rinv;        // 1/rho
+    ShareXF sx;
+    ShareYF sy;
+};
+
+// Rule for this section: a difference of two products that cancels exactly in the strict form
+// (equal face states on opposite faces, equal neighbours) must cancel exactly here too, because
+// the unknown's coefficient switches between 1 and rho on "phi == 0" and an update that turns an
+// exact zero into 1e-17 changes the next sweep at O(1).  So products are rounded before they are
+// subtracted (no contraction of a*b - c*d); fma is used only to combine already-formed
+// differences with constants, and inside per-cell functions of a single state.
+CFD_HD void phaseA2f(const FastConsts& k, const double c[NF2], const double e[NF2], const double w[NF2],
+                     const double n[NF2], const double s[NF2], PhaseAF& o) {
+    double fE[NF2], fW[NF2], fN[NF2], fS[NF2];
+    for (int q = 0; q < NF2; ++q) {
+        const double hx = half_slope(e[q], c[q], w[q]);
+        const double hy = half_slope(n[q], c[q], s[q]);
+        fE[q] = c[q] + hx; fW[q] = c[q] - hx;
+        fN[q] = c[q] + hy; fS[q] = c[q] - hy;
+    }
+    const double muC = mu_fast(k, c[F2_T]);
+    const double muE = mu_fast(k, fE[F2_T]), muW = mu_fast(k, fW[F2_T]);
+    const double muN = mu_fast(k, fN[F2_T]), muS = mu_fast(k, fS[F2_T]);
+    const double pE = (k.R * fE[F2_T]) * fE[F2_RHO], pW = (k.R * fW[F2_T]) * fW[F2_RHO];
+    const double pN = (k.R * fN[F2_T]) * fN[F2_RHO], pS = (k.R * fS[F2_T]) * fS[F2_RHO];
+    const double mE = fE[F2_RHO] * fE[F2_U], mW = fW[F2_RHO] * fW[F2_U];
+    const double mN = fN[F2_RHO] * fN[F2_V], mS = fS[F2_RHO] * fS[F2_V];
+
+    // flux differences per direction (products rounded, then subtracted)
+    const double dRx = mE - mW, dRy = mN - mS;
+    const double dUx = (mE * fE[F2_U] - mW * fW[F2_U]) + (pE - pW), dUy = mN * fN[F2_U] - mS * fS[F2_U];
+    const double dVx = mE * fE[F2_V] - mW * fW[F2_V], dVy = (mN * fN[F2_V] - mS * fS[F2_V]) + (pN - pS);
+    const double dTx = k.cv * (mE * fE[F2_T] - mW * fW[F2_T]) + (pE * fE[F2_U] - pW * fW[F2_U]);
+    const double dTy = k.cv * (mN * fN[F2_T] - mS * fS[F2_T]) + (pN * fN[F2_V] - pS * fS[F2_V]);
+    const double dDx = mE * fE[F2_DYE] - mW * fW[F2_DYE], dDy = mN * fN[F2_DYE] - mS * fS[F2_DYE];
+    o.div[E2_RHO] = fma(k.rcx, dRx, k.rcy * dRy);
+    o.div[E2_U] = fma(k.rcx, dUx, k.rcy * dUy);
+    o.div[E2_V] = fma(k.rcx, dVx, k.rcy * dVy);
+    o.div[E2_T] = fma(k.rcx, dTx, k.rcy * dTy);
+    o.div[E2_DYE] = fma(k.rcx, dDx, k.rcy * dDy);
+    o.phi[E2_RHO] = c[F2_RHO]; o.phi[E2_U] = c[F2_U]; o.phi[E2_V] = c[F2_V];
+    o.phi[E2_T] = c[F2_T];     o.phi[E2_DYE] = c[F2_DYE];
+    o.rinv = fast_rcp(c[F2_RHO]);
+
+    const double a = muC * c[F2_U], b = muC * c[F2_V], g = muC * c[F2_DYE];
+    const double a2 = a * a, b2 = b * b, kt = k.k * c[F2_T];
+    o.sx.a = a; o.sx.b = b; o.sx.g = g;
+    o.sy.a = a; o.sy.b = b; o.sy.g = g;
+    o.sx.px = (kt + fma(k.c83h, a2, k.c83n * a)) + fma(0.5, b2, -b);
+    o.sy.py = (kt + fma(k.c83h, b2, k.c83n * b)) + fma(0.5, a2, -a);
+    const double aN = muN * fN[F2_U], aS = muS * fS[F2_U], bN = muN * fN[F2_V], bS = muS * fS[F2_V];
+    const double aE = muE * fE[F2_U], aW = muW * fW[F2_U], bE = muE * fE[F2_V], bW = muW * fW[F2_V];
+    o.sx.dna = aN - aS;
+    o.sx.dnb = bN - bS;
+    o.sx.q = ((aN * fN[F2_V] - aS * fS[F2_V]) - o.sx.dna) - (fN[F2_V] - fS[F2_V]);
+    o.sy.dea = aE - aW;
+    o.sy.deb = bE - bW;
+}
+
+CFD_HD void phaseB2f(const FastConsts& k, const PhaseAF& C, const ShareXF& XE, const ShareXF& XW,
+                     const ShareYF& YN, const ShareYF& YS, double out[5]) {
+    const ShareXF& X = C.sx;
+    const ShareYF& Y = C.sy;
+    // second differences and cross differences, per unit volume
+    const double rU = fma(k.kxxm, (XE.a + XW.a) - 2.0 * X.a,
+                      fma(k.kyy, (YN.a + YS.a) - 2.0 * Y.a,
+                      fma(k.kxy, XE.dnb - XW.dnb, k.kxym * (YN.deb - YS.deb))));
+    const double rV = fma(k.kxx, (XE.b + XW.b) - 2.0 * X.b,
+                      fma(k.kyym, (YN.b + YS.b) - 2.0 * Y.b,
+                      fma(k.kxy, YN.dea - YS.dea, k.kxym * (XE.dna - XW.dna))));
+    const double rT = fma(k.kxx, (XE.px + XW.px) - 2.0 * X.px,
+                      fma(k.kyy, (YN.py + YS.py) - 2.0 * Y.py, k.kxy * (XE.q - XW.q)));
+    const double rD = k.dyef * fma(k.kxx, (XE.g + XW.g) - 2.0 * X.g, k.kyy * ((YN.g + YS.g) - 2.0 * Y.g));
+    const double gU = C.div[E2_U] - rU, gV = C.div[E2_V] - rV, gT = C.div[E2_T] - rT, gD = C.div[E2_DYE] - rD;
+    // increment form; where phi is exactly zero the unknown's coefficient is 1 instead of rho
+    out[E2_RHO] = C.phi[E2_RHO] - C.div[E2_RHO];
+    out[E2_U] = C.phi[E2_U] != 0.0 ? fma(-gU, C.rinv, C.phi[E2_U]) : -gU;
+    out[E2_V] = C.phi[E2_V] != 0.0 ? fma(-gV, C.rinv, C.phi[E2_V]) : -gV;
+    out[E2_T] = C.phi[E2_T] != 0.0 ? fma(-gT, C.rinv * k.rcv, C.phi[E2_T]) : -gT;
+    out[E2_DYE] = C.phi[E2_DYE] != 0.0 ? fma(-gD, C.rinv, C.phi[E2_DYE]) : -gD;
+}
+
+// ------------------------------------------------------------------------------------------
 // General 3-D case.  Field order of the 3-D arrays: U, V, W, Density, Temperature, Dye.
 // Directions d = 0,1,2 (X,Y,Z); faces of direction d: index 0 = upper (East/North/Top),
 // 1 = lower (West/South/Bottom).  Also valid for nz == 1 with W != 0 (Top/Bottom neighbours are

@@ -1,0 +1,124 @@
+{-# LANGUAGE ForeignFunctionInterface #-}
+-- | Binding of libcfdhip.so for the reference program, and the marshalling of its AdjGraph.
+--
+-- STATUS: source only.  No GHC exists in the environment this library was built in, so this
+-- module has never been compiled; it is written against the reference's types
+-- (SolutionDomain.AdjGraph / AdjNode / Grids) and include/cfd_hip.h.
+--
+-- Use: in Main.hs replace the body of runTimeSteps_Print's fold with CfdHip.runTimeStepsHip
+-- (see INTEGRATION.md).  The solve loop, the printing and initialGrid_adj stay in Haskell.
+module CfdHip
+    ( HipGraph, withHipGraph, hipRunSingleStep, hipTotalDensity, hipTime, hipReadSlot, runTimeStepsHip
+    ) where
+
+import Control.Monad (forM, forM_, when)
+import Data.Maybe (fromMaybe)
+import qualified Data.Vector as V
+import qualified Data.Vector.Storable as SV
+import Data.Word (Word8)
+import Foreign
+import Foreign.C.String (CString, peekCString)
+import Foreign.C.Types
+
+import SolutionDomain
+
+-- struct cfd_params (include/cfd_hip.h): 3 x int32, pad, 10 x double, 4 x int32 = 112 bytes
+data Params = Params
+    { pNx, pNy, pNz :: !Int32
+    , pDx, pDy, pDz, pDt, pLambda, pSuth, pR, pCv, pK, pDyeF :: !Double
+    , pDevice, pFlags, pGhostLo, pGhostHi :: !Int32 }
+
+instance Storable Params where
+    sizeOf _ = 112
+    alignment _ = 8
+    peek _ = error "Params: peek not needed"
+    poke p (Params nx ny nz dx dy dz dt la su r cv k dy' dev fl gl gh) = do
+        pokeByteOff p 0 nx >> pokeByteOff p 4 ny >> pokeByteOff p 8 nz
+        forM_ (zip [16, 24 ..] [dx, dy, dz, dt, la, su, r, cv, k, dy']) $ \(o, v) -> pokeByteOff p o v
+        pokeByteOff p 96 dev >> pokeByteOff p 100 fl >> pokeByteOff p 104 gl >> pokeByteOff p 108 gh
+
+data CfdHandle
+newtype HipGraph = HipGraph (Ptr CfdHandle)
+
+foreign import ccall safe "cfd_create"
+    c_create :: Ptr Params -> Ptr (Ptr Double) -> Ptr Word8 -> Ptr (Ptr CfdHandle) -> IO CInt
+foreign import ccall safe "cfd_destroy" c_destroy :: Ptr CfdHandle -> IO ()
+foreign import ccall safe "cfd_step" c_step :: Ptr CfdHandle -> CInt -> IO CInt
+foreign import ccall safe "cfd_sweep" c_sweep :: Ptr CfdHandle -> CInt -> IO CInt
+foreign import ccall safe "cfd_time_filter" c_filter :: Ptr CfdHandle -> IO CInt
+foreign import ccall safe "cfd_total_density" c_density :: Ptr CfdHandle -> Ptr Double -> IO CInt
+foreign import ccall safe "cfd_read_fields" c_read :: Ptr CfdHandle -> CInt -> Ptr (Ptr Double) -> IO CInt
+foreign import ccall safe "cfd_time" c_time :: Ptr CfdHandle -> Ptr CInt -> Ptr CInt -> IO CInt
+foreign import ccall safe "cfd_last_error" c_last_error :: IO CString
+
+check :: String -> CInt -> IO ()
+check what rc = when (rc /= 0) $ do
+    msg <- c_last_error >>= peekCString
+    ioError (userError (what ++ ": libcfdhip error " ++ show rc ++ ": " ++ msg))
+
+-- | Flattens slot currModTime of an AdjGraph: seven property vectors in propIndex order, the
+-- active mask, and the uniform geometry read from node 0 (every node carries the same copies,
+-- SolutionDomain.hs:279-289).
+marshalGraph :: AdjGraph -> (Params, [SV.Vector Double], SV.Vector Word8)
+marshalGraph (AdjGraph (Grids g) cmt _) =
+    let nodes = g V.! cmt
+        n0 = nodes V.! 0
+        len d = fromMaybe (error "edgeLen") (edgeLen n0 V.! d)
+        prop i = SV.generate (V.length nodes) $ \j ->
+            fromMaybe (error "property") (property (nodes V.! j) V.! i)
+        act = SV.generate (V.length nodes) $ \j -> if active (nodes V.! j) then 1 else 0
+        i32 = fromIntegral :: Int -> Int32
+        params = Params (i32 (maxPos X + 1)) (i32 (maxPos Y + 1)) (i32 (maxPos Z + 1))
+                        (len 0) (len 1) (len 2) timeStep sutherlandLambda sutherlandConstant
+                        gasConstantR specificHeatCv 0.025 0.001 (-1) 0 0 0
+    in (params, map prop [0 .. 6], act)
+
+withHipGraph :: AdjGraph -> (HipGraph -> IO a) -> IO a
+withHipGraph g body =
+    let (params, fields, act) = marshalGraph g
+    in with params $ \pp ->
+       withMany SV.unsafeWith fields $ \fps ->
+       withArray fps $ \fpp ->
+       SV.unsafeWith act $ \ap ->
+       alloca $ \hp -> do
+           c_create pp fpp ap hp >>= check "cfd_create"
+           h <- peek hp
+           r <- body (HipGraph h)
+           c_destroy h
+           return r
+
+-- | runSingleStep (Main.hs:192-200)
+hipRunSingleStep :: HipGraph -> IO ()
+hipRunSingleStep (HipGraph h) = c_step h 1 >>= check "cfd_step"
+
+-- | totalDensity (Main.hs:269-270)
+hipTotalDensity :: HipGraph -> IO Double
+hipTotalDensity (HipGraph h) = alloca $ \p -> c_density h p >>= check "cfd_total_density" >> peek p
+
+-- | (currModTime, currAbsTime)
+hipTime :: HipGraph -> IO (Int, Int)
+hipTime (HipGraph h) = alloca $ \a -> alloca $ \b -> do
+    c_time h a b >>= check "cfd_time"
+    (,) <$> (fromIntegral <$> peek a) <*> (fromIntegral <$> peek b)
+
+-- | Seven property vectors of slot currModTime - slotRel.
+hipReadSlot :: HipGraph -> Int -> Int -> IO [SV.Vector Double]
+hipReadSlot (HipGraph h) n slotRel = do
+    bufs <- forM [0 .. 6 :: Int] $ \_ -> mallocForeignPtrArray n
+    withMany withForeignPtr bufs $ \ps -> withArray ps $ \pp ->
+        c_read h (fromIntegral slotRel) pp >>= check "cfd_read_fields"
+    return [SV.unsafeFromForeignPtr0 b n | b <- bufs]
+
+-- | The solve loop of Main.hs:278-306 with the update on the GPU; prints the same five lines.
+runTimeStepsHip :: AdjGraph -> Int -> IO ()
+runTimeStepsHip g0 nsteps = withHipGraph g0 $ \hg ->
+    forM_ [0 .. nsteps - 1] $ \step -> do
+        hipRunSingleStep hg
+        (cmt, cat) <- hipTime hg
+        td <- hipTotalDensity hg
+        putStrLn $ show (V.length (grids (allNodes g0) V.! 0))
+        putStrLn $ "step: " ++ show step
+        putStrLn $ "timeLevel: " ++ show cmt
+        putStrLn $ "timeLevelAbsolute: " ++ show cat
+        putStrLn $ "totalDensity: " ++ show td
+        putStrLn " "

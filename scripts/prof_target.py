@@ -1,0 +1,15 @@
+"""Profiling target: N sweeps of the 4096 x 4096 synthetic grid (kernel selected by FLAGS / CFD_VARIANT)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cfd_amd import cases
+from cfd_amd.solver import AdjGraph
+nx = int(os.environ.get("NX", 4096)); ny = int(os.environ.get("NY", 4096))
+params, fields, active = cases.synthetic_2d(nx, ny, seed=1)
+params["dt"] = 1e-7
+params["flags"] = int(os.environ.get("FLAGS", "4"))
+g = AdjGraph(params, fields, active)
+for i in range(int(os.environ.get("NSWEEP", "6"))):
+    g.sweep(i % 3 == 0)
+g.time_filter()
+g.sync()
+print("done", g.kernel_name())

@@ -8,12 +8,15 @@ params, fields, active = cases.synthetic_2d(nx, ny, seed=1)
 for spec in sys.argv[1:]:
     v, ch = spec.split(":")
     os.environ["CFD_VARIANT"] = v; os.environ["CFD_CHUNK"] = ch
-    p = dict(params); p["flags"] = 1 if v == "s" else 0
-    if v == "s": os.environ["CFD_VARIANT"] = "0"
+    fl = 0
+    if v.startswith("f"): fl |= 4; v = v[1:]
+    if v == "s": fl |= 1; v = "0"
+    os.environ["CFD_VARIANT"] = v
+    p = dict(params); p["flags"] = fl
     g = AdjGraph(p, fields, active)
     for _ in range(3): g.sweep(False)
     g.set_timing(True); g.sweep_timing()
     for _ in range(10): g.sweep(False)
     ms, n = g.sweep_timing()
-    print("variant %s chunk %s: %.3f ms/sweep  %.2f Gcell/s  %.0f GB/s" % (v, ch, ms / n, nx * ny / (ms / n) / 1e6, nx * ny * 81 / (ms / n) / 1e6), flush=True)
+    print("variant %s chunk %s: %.3f ms/sweep  %.2f Gcell/s  %.0f GB/s" % (spec.split(":")[0], ch, ms / n, nx * ny / (ms / n) / 1e6, nx * ny * 81 / (ms / n) / 1e6), flush=True)
     g.close()

@@ -56,3 +56,16 @@ def rel_err(a, b):
     scale = np.max(np.abs(b))
     d = np.max(np.abs(a - b))
     return 0.0 if d == 0 else float(d / scale) if scale > 0 else float("inf")
+
+
+def field_errors(got, want):
+    """Per-property error of two 7-field lists, each relative to its field's scale: max|want| for
+    Density, Temperature, Dye; the largest velocity component magnitude for U, V, W (they are
+    components of one vector and carry the same absolute rounding noise)."""
+    vs = max(float(np.max(np.abs(want[k]))) for k in (0, 1, 2))
+    out = []
+    for k in range(7):
+        sc = vs if k < 3 else float(np.max(np.abs(want[k])))
+        d = float(np.max(np.abs(np.asarray(got[k]) - np.asarray(want[k]))))
+        out.append(0.0 if d == 0 else d / sc if sc > 0 else float("inf"))
+    return out
