@@ -98,6 +98,8 @@ struct MathStrict2 {
     using SX = ShareX2;
     using SY = ShareY2;
     static constexpr int NSY = 12;
+    // stored U, V, Dye of the cell (which = 0, 1, 2)
+    __device__ __forceinline__ static double own(const PA& a, int which) { return a.own[which]; }
     __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* e, const double* w,
                                                   const double* n, const double* s, PA& o) {
         phaseA2(K, c, e, w, n, s, o);
@@ -124,6 +126,9 @@ struct MathFast2 {
     using SX = ShareXF;
     using SY = ShareYF;
     static constexpr int NSY = 6;
+    __device__ __forceinline__ static double own(const PA& a, int which) {
+        return which == 0 ? a.phi[E2_U] : (which == 1 ? a.phi[E2_V] : a.phi[E2_DYE]);
+    }
     __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* e, const double* w,
                                                   const double* n, const double* s, PA& o) {
         phaseA2f(K, c, e, w, n, s, o);
@@ -140,24 +145,28 @@ struct MathFast2 {
     }
 };
 
+// Row addressing: `x` is uniform across the block, so the plane base stays in scalar registers and
+// a lane adds only a 32-bit element offset.
 __device__ __forceinline__ void load5(const double* __restrict__ src, long plane5, int ny, int x, int y,
                                       double v[NF2]) {
-    const double* p = src + (long)x * plane5 + y;
+    const double* __restrict__ row = src + (long)x * plane5;
 #pragma unroll
-    for (int f = 0; f < NF2; ++f) v[f] = p[(long)f * ny];
+    for (int f = 0; f < NF2; ++f) v[f] = row[(unsigned)(f * ny + y)];
 }
 
 __device__ __forceinline__ void store5(const double* __restrict__ src, double* __restrict__ dst,
                                        const uint8_t* __restrict__ active, long plane5, int ny, int x, int y,
                                        const double o[5]) {
-    const bool act = active[(long)x * ny + y] != 0;
-    const double* sp = src + (long)x * plane5 + y;
-    double* dp = dst + (long)x * plane5 + y;
-    dp[(long)F2_RHO * ny] = o[E2_RHO];
-    dp[(long)F2_T * ny] = o[E2_T];
-    dp[(long)F2_U * ny] = act ? o[E2_U] : sp[(long)F2_U * ny];
-    dp[(long)F2_V * ny] = act ? o[E2_V] : sp[(long)F2_V * ny];
-    dp[(long)F2_DYE * ny] = act ? o[E2_DYE] : sp[(long)F2_DYE * ny];
+    const bool act = (active + (long)x * ny)[(unsigned)y] != 0;
+    const double* __restrict__ sp = src + (long)x * plane5;
+    double* __restrict__ dp = dst + (long)x * plane5;
+    const unsigned iR = F2_RHO * ny + y, iT = F2_T * ny + y, iU = F2_U * ny + y, iV = F2_V * ny + y,
+                   iD = F2_DYE * ny + y;
+    dp[iR] = o[E2_RHO];
+    dp[iT] = o[E2_T];
+    dp[iU] = act ? o[E2_U] : sp[iU];
+    dp[iV] = act ? o[E2_V] : sp[iV];
+    dp[iD] = act ? o[E2_DYE] : sp[iD];
 }
 
 // One thread per cell; every thread evaluates phase A for its cell and again for its four face
@@ -256,6 +265,27 @@ sweep3d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict
     dp[(long)F3_DYE * plane] = act ? o[E3_DYE] : sp[(long)F3_DYE * plane];
 }
 
+// Buffer-resource addressing: one 128-bit descriptor per x-plane (built from block-uniform values,
+// so it lives in scalar registers), a per-lane 32-bit byte offset for the column, and a scalar
+// byte offset for the field.  No per-lane 64-bit address arithmetic; an out-of-range per-lane
+// offset makes the hardware drop the access, which is how non-writing lanes are masked.
+typedef int cfd_v2i __attribute__((ext_vector_type(2)));
+
+struct PlaneRef {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ PlaneRef(const void* base, unsigned bytes)
+        : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000)) {}
+    __device__ __forceinline__ double ld(unsigned voff, unsigned soff) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    }
+    __device__ __forceinline__ unsigned char ldb(unsigned voff) const {
+        return __builtin_amdgcn_raw_buffer_load_b8(r, voff, 0, 0);
+    }
+    __device__ __forceinline__ void st(unsigned voff, unsigned soff, double x) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cfd_v2i, x), r, voff, soff, 0);
+    }
+};
+
 // Tiled sweep ("march"): a block owns NT-2 adjacent columns (lanes run along y, the contiguous
 // index) plus one halo column on each side, and walks a chunk of x-planes.  Each thread keeps
 // its column's phase-A results for rows x-1, x, x+1 in registers, so the East/West neighbour
@@ -263,7 +293,8 @@ sweep3d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict
 // lanes through a double-buffered LDS tile.  Phase A is evaluated exactly once per cell (plus
 // the two halo columns and two extra rows per chunk), and every cell is read from HBM once.
 //
-//   iteration j:  phase A of row j  ->  publish its y-products in lds[j&1]
+//   iteration j:  issue the loads the NEXT iteration needs (row j+2, N/S of row j+1, mask of row j)
+//                 phase A of row j  ->  publish its y-products in lds[j&1]
 //                 phase B of row j-1 (centre = row j-1, East = row j, West = row j-2,
 //                                     North/South = lds[(j-1)&1] of lanes t+1 / t-1)
 //                 one barrier
@@ -282,17 +313,27 @@ sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;      // first and last row whose phase A is needed
     const int j1 = xe < xhi ? xe : xhi;
     const long plane5 = (long)NF2 * ny;
+    const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
+    const unsigned vc = (unsigned)cy * 8u, vn = (unsigned)yn * 8u, vs = (unsigned)ys * 8u;
+    const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
     auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
+    auto load_row = [&](int x, unsigned voff, double v[NF2]) {
+        const PlaneRef p(src + (long)x * plane5, pbytes);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) v[f] = p.ld(voff, (unsigned)f * fstride);
+    };
+    auto load_act = [&](int x) { return PlaneRef(active + (long)x * ny, (unsigned)ny).ldb((unsigned)cy); };
 
     double rw[NF2], rc[NF2], re[NF2], rn[NF2], rs[NF2];
-    load5(src, plane5, ny, clampx(j0 - 1), cy, rw);
-    load5(src, plane5, ny, j0, cy, rc);
-    load5(src, plane5, ny, clampx(j0 + 1), cy, re);
-    load5(src, plane5, ny, j0, yn, rn);
-    load5(src, plane5, ny, j0, ys, rs);
+    load_row(clampx(j0 - 1), vc, rw);
+    load_row(j0, vc, rc);
+    load_row(clampx(j0 + 1), vc, re);
+    load_row(j0, vn, rn);
+    load_row(j0, vs, rs);
 
     typename M::PA Ac;      // phase A of row j-1
     typename M::SX Xw;      // x-products of row j-2
+    unsigned char act_c = 1; // mask of row j-1
 
     auto emit = [&](int x, const typename M::SX& XE) {
         // phase B of row x; Ac holds its phase A, lds[x&1] its neighbours' y-products
@@ -302,37 +343,60 @@ sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         M::get_sy(&lds[x & 1][0][tsn], NT, YS);
         double o[5];
         M::phaseB(K, Ac, XE, Xw, YN, YS, o);
-        if (writer) store5(src, dst, active, plane5, ny, x, y, o);
-    };
-    auto advance = [&](int j) {
-        // shift the raw-value window one row: (rw, rc, re) <- rows (j, j+1, j+2); N/S of row j+1
-        const int jn = clampx(j + 1);
-#pragma unroll
-        for (int f = 0; f < NF2; ++f) { rw[f] = rc[f]; rc[f] = re[f]; }
-        load5(src, plane5, ny, clampx(j + 2), cy, re);
-        load5(src, plane5, ny, jn, yn, rn);
-        load5(src, plane5, ny, jn, ys, rs);
+        const bool act = act_c != 0;
+        const PlaneRef d(dst + (long)x * plane5, pbytes);
+        d.st(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
+        d.st(vst, (unsigned)F2_T * fstride, o[E2_T]);
+        d.st(vst, (unsigned)F2_U * fstride, act ? o[E2_U] : M::own(Ac, 0));
+        d.st(vst, (unsigned)F2_V * fstride, act ? o[E2_V] : M::own(Ac, 1));
+        d.st(vst, (unsigned)F2_DYE * fstride, act ? o[E2_DYE] : M::own(Ac, 2));
     };
 
     // first row: nothing to emit yet.  Its x-products also stand in for the row before it, which
     // is exactly the clamp-to-self rule when that row lies outside the domain, and is replaced
     // before use otherwise.
-    M::phaseA(K, rc, re, rw, rn, rs, Ac);
-    M::put_sy(&lds[j0 & 1][0][t], NT, Ac.sy);
-    Xw = Ac.sx;
-    advance(j0);
-    __syncthreads();
+    {
+        double re2[NF2], rn2[NF2], rs2[NF2];
+        const int jn = clampx(j0 + 1);
+        load_row(clampx(j0 + 2), vc, re2);
+        load_row(jn, vn, rn2);
+        load_row(jn, vs, rs2);
+        act_c = load_act(j0);
+        M::phaseA(K, rc, re, rw, rn, rs, Ac);
+        M::put_sy(&lds[j0 & 1][0][t], NT, Ac.sy);
+        Xw = Ac.sx;
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { rw[f] = rc[f]; rc[f] = re[f]; re[f] = re2[f]; rn[f] = rn2[f]; rs[f] = rs2[f]; }
+        __syncthreads();
+    }
 
     for (int j = j0 + 1; j <= j1; ++j) {
+        double re2[NF2], rn2[NF2], rs2[NF2];
+        const int jn = clampx(j + 1);
+        unsigned char act_n;
+        if (PREFETCH) {
+            load_row(clampx(j + 2), vc, re2);
+            load_row(jn, vn, rn2);
+            load_row(jn, vs, rs2);
+            act_n = load_act(j);
+        }
         typename M::PA An;
         M::phaseA(K, rc, re, rw, rn, rs, An);
         M::put_sy(&lds[j & 1][0][t], NT, An.sy);
-        advance(j);
+        if (!PREFETCH) {
+            load_row(clampx(j + 2), vc, re2);
+            load_row(jn, vn, rn2);
+            load_row(jn, vs, rs2);
+            act_n = load_act(j);
+        }
         const int x = j - 1;
         if (x >= xs) emit(x, An.sx);               // block-uniform
         __syncthreads();
         Xw = Ac.sx;
         Ac = An;
+        act_c = act_n;
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { rw[f] = rc[f]; rc[f] = re[f]; re[f] = re2[f]; rn[f] = rn2[f]; rs[f] = rs2[f]; }
     }
     // last owned row of the domain: its clamped East neighbour is the cell itself
     if (j1 < xe) emit(xe - 1, Ac.sx);

@@ -25,6 +25,7 @@
 #pragma once
 
 #include <math.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define CFD_HD __host__ __device__ __forceinline__
@@ -69,15 +70,22 @@ inline SweepConsts make_consts(double dx, double dy, double dz, double dt, doubl
     return c;
 }
 
+// Upper 32 bits of a double (sign, exponent, top of the mantissa).
+CFD_HD int hi_word(double x) {
+    long long b;
+    memcpy(&b, &x, sizeof b);
+    return (int)(b >> 32);
+}
+
 // superbee a b: zero unless a and b are both > 0 or both < 0, else
-// sign * min(max(|a|,|b|), min(2|a|,2|b|)).
+// sign * min(max(|a|,|b|), min(2|a|,2|b|)).  Branch-free: the sign test is an integer test on
+// the two sign bits plus "the smaller magnitude is non-zero".  (For NaN inputs the reference's
+// getSign calls NaN negative; NaN fields are outside what this code reproduces.)
 CFD_HD double superbee(double a, double b) {
     const double aa = fabs(a), ab = fabs(b);
-    const double hi = aa <= ab ? ab : aa;
-    const double lo = aa <= ab ? aa : ab;
-    const double lo2 = 2.0 * lo;
-    const double m = hi <= lo2 ? hi : lo2;
-    const bool same = (a > 0.0 && b > 0.0) || (a < 0.0 && b < 0.0);
+    const double hi = fmax(aa, ab), lo = fmin(aa, ab);
+    const double m = fmin(hi, lo + lo);
+    const bool same = ((hi_word(a) ^ hi_word(b)) >= 0) & (lo > 0.0);
     return same ? copysign(m, a) : 0.0;
 }
 
@@ -143,6 +151,7 @@ struct ShareY2 {
 struct PhaseA2 {
     double lhs[5];      // complete left-hand-side constant sums
     double aU[5];       // unknown coefficients (already times the cell volume)
+    double own[3];      // the cell's stored U, V, Dye (kept where the cell is inactive)
     ShareX2 sx;
     ShareY2 sy;
 };
@@ -174,6 +183,7 @@ CFD_HD void phaseA2(const SweepConsts& k, const double c[NF2], const double e[NF
     // mass fluxes shared by several equations: (rho_f u_f) on E/W, (rho_f v_f) on N/S
     const double mE = rE * uE, mW = rW * uW, mN = rN * vN, mS = rS * vS;
 
+    o.own[0] = c[F2_U]; o.own[1] = c[F2_V]; o.own[2] = c[F2_DYE];
     double F, l;
     // ---- continuity: d(rho)/dt + div(rho u)
     F = c[F2_RHO];
