@@ -9,6 +9,16 @@ case scaled to a 2-D 4096 x 4096 synthetic grid (cases.synthetic_2d, seed 1).  F
 grid is slab-decomposed along x, one process per GPU, 4096 planes per GPU (weak scaling), with
 the halo planes exchanged before every sweep.
 
+Time step: the reference ships dt = 1e-5, with which its explicit scheme amplifies every
+perturbation until the fields overflow (NaN within ~20 steps on this grid); the benchmark uses
+the alternative the reference's source records next to it, dt = 1e-7, with which a 1000-step
+run stays finite.  Kernel time does not depend on dt.
+
+Arithmetic: --arith fast (default) runs the re-associated form (<= 1e-13 of the field scale per
+sweep against the strict form, see tests); --arith strict runs the reference's operation order
+(bit-identical to the CPU oracle).  The strict kernel is also timed on a few steps and reported
+under "strict" in the same JSON line.
+
 Prints ONE JSON line (rank 0): whole-job cell-updates/s with the inputs already resident in
 HBM, the sweep kernel's roofline object (HIP-event kernel time measured in the timed region)
 and, at N = 1, the CPU baseline (the C restatement under oracle/, timed on a bounded sample).
@@ -37,7 +47,9 @@ def parse():
     ap.add_argument("--nx", type=int, default=4096, help="x-planes per GPU")
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--nz", type=int, default=1)
-    ap.add_argument("--flags", type=int, default=0, help="cfd_params.flags (1 = one-thread-per-cell kernel)")
+    ap.add_argument("--arith", choices=("fast", "strict"), default="fast")
+    ap.add_argument("--dt", type=float, default=1e-7)
+    ap.add_argument("--flags", type=int, default=0, help="extra cfd_params.flags (1 = one-thread-per-cell kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="edge of the square CPU-baseline sample grid")
     return ap.parse_args()
@@ -103,9 +115,9 @@ def main():
     else:
         params, fields, active = cases.synthetic_3d(a.nx, a.ny, a.nz, seed=3 + rank)
     params["device"] = local_rank
-    params["flags"] = a.flags
+    params["dt"] = a.dt
+    params["flags"] = a.flags | (4 if a.arith == "fast" else 0)
     g = SlabGraph(params, fields, active, rank=rank, world=world)
-    del fields
 
     def barrier():
         if world > 1:
@@ -125,18 +137,45 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = g.graph.sweep_timing(reset=True)
     g.graph.set_timing(False)
+    KERNEL_NAME = g.graph.kernel_name()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     cells_per_gpu = a.nx * a.ny * a.nz
+    final_density = g.total_density()
+
+    strict = None
+    if a.arith == "fast" and world == 1:
+        # the strict-order kernel on the same workload, a few steps, for the record
+        g.close()
+        params["flags"] = a.flags
+        gs = SlabGraph(params, fields, active, rank=rank, world=world)
+        gs.step(1)
+        barrier_s = lambda: (torch.cuda.synchronize(), gs.sync())
+        barrier_s()
+        gs.graph.set_timing(True)
+        gs.graph.sweep_timing(reset=True)
+        ts = time.perf_counter()
+        nstrict = max(2, min(5, a.steps))
+        gs.step(nstrict)
+        barrier_s()
+        es = time.perf_counter() - ts
+        kms, kl = gs.graph.sweep_timing(reset=True)
+        strict = {"value": cells_per_gpu * SWEEPS_PER_STEP * nstrict / es, "unit": "cell-updates/s",
+                  "steps": nstrict, "kernel": gs.graph.kernel_name(), "avg_launch_ms": kms / max(kl, 1),
+                  "achieved_GBps": cells_per_gpu * (BYTES_PER_UPDATE_2D if gs.graph.live_fields == 5
+                                                    else BYTES_PER_UPDATE_3D) / (kms / 1e3 / max(kl, 1)) / 1e9}
+        gs.close()
+    del fields
     updates = cells_per_gpu * world * SWEEPS_PER_STEP * a.steps
-    bytes_per_update = BYTES_PER_UPDATE_2D if g.graph.live_fields == 5 else BYTES_PER_UPDATE_3D
+    bytes_per_update = BYTES_PER_UPDATE_2D if two_d else BYTES_PER_UPDATE_3D
     avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
     achieved = cells_per_gpu * bytes_per_update / avg_kernel_s / 1e9
     workload = ("synthetic_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if two_d else \
         ("synthetic_3d %dx%dx%d per GPU" % (a.nx, a.ny, a.nz))
+    kernel_name = KERNEL_NAME
     out = {
         "metric": "fp64 cell-updates/sec",
         "value": updates / elapsed,
@@ -152,17 +191,21 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload, "cells_per_gpu": cells_per_gpu, "sweeps_per_step": SWEEPS_PER_STEP,
                    "filter_passes_per_step": 1, "decomposition": "x-slabs, %d rank(s)" % world,
-                   "kernel": g.graph.kernel_name()},
+                   "kernel": kernel_name, "arithmetic": a.arith, "dt": a.dt,
+                   "fields_finite_at_end": bool(final_density == final_density and abs(final_density) != float("inf"))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(workload),
                      "kernel": "sweep", "bytes_per_cell_update": bytes_per_update,
                      "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches},
     }
+    if strict is not None:
+        out["strict"] = strict
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         print(json.dumps(out), flush=True)
-    g.close()
+    if strict is None:
+        g.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -12,6 +12,7 @@
 // receives a sweep which does not advance time (the reference rebuilds slot t from a snapshot
 // of slot t; here the result lands in scratch and the two buffers trade roles).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -331,75 +332,65 @@ sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     load_row(j0, vn, rn);
     load_row(j0, vs, rs);
 
-    typename M::PA Ac;      // phase A of row j-1
-    typename M::SX Xw;      // x-products of row j-2
-    unsigned char act_c = 1; // mask of row j-1
+    // Phase-A results of three consecutive rows rotate through P0, P1, P2 (the loop is unrolled by
+    // three so that the roles "row j", "row j-1", "row j-2" are fixed per copy and nothing is moved).
+    typename M::PA P0, P1, P2;
+    unsigned char act_c = 1;    // mask of row j-1
 
-    auto emit = [&](int x, const typename M::SX& XE) {
-        // phase B of row x; Ac holds its phase A, lds[x&1] its neighbours' y-products
+    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW) {
+        // phase B of row x; C holds its phase A, lds[x&1] its neighbours' y-products
         typename M::SY YN, YS;
         const int tn = t + 1 > NT - 1 ? NT - 1 : t + 1, tsn = t - 1 < 0 ? 0 : t - 1;
         M::get_sy(&lds[x & 1][0][tn], NT, YN);
         M::get_sy(&lds[x & 1][0][tsn], NT, YS);
         double o[5];
-        M::phaseB(K, Ac, XE, Xw, YN, YS, o);
+        M::phaseB(K, C, XE, XW, YN, YS, o);
         const bool act = act_c != 0;
         const PlaneRef d(dst + (long)x * plane5, pbytes);
         d.st(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
         d.st(vst, (unsigned)F2_T * fstride, o[E2_T]);
-        d.st(vst, (unsigned)F2_U * fstride, act ? o[E2_U] : M::own(Ac, 0));
-        d.st(vst, (unsigned)F2_V * fstride, act ? o[E2_V] : M::own(Ac, 1));
-        d.st(vst, (unsigned)F2_DYE * fstride, act ? o[E2_DYE] : M::own(Ac, 2));
+        d.st(vst, (unsigned)F2_U * fstride, act ? o[E2_U] : M::own(C, 0));
+        d.st(vst, (unsigned)F2_V * fstride, act ? o[E2_V] : M::own(C, 1));
+        d.st(vst, (unsigned)F2_DYE * fstride, act ? o[E2_DYE] : M::own(C, 2));
+    };
+    // one row: phase A of row j into An, then phase B of row j-1 (centre Ac, West Aw)
+    auto row = [&](int j, typename M::PA& An, const typename M::PA& Ac, const typename M::PA& Aw, bool first) {
+        double re2[NF2], rn2[NF2], rs2[NF2];
+        const int jn = clampx(j + 1);
+        load_row(clampx(j + 2), vc, re2);
+        load_row(jn, vn, rn2);
+        load_row(jn, vs, rs2);
+        const unsigned char act_n = load_act(j);
+        M::phaseA(K, rc, re, rw, rn, rs, An);
+        M::put_sy(&lds[j & 1][0][t], NT, An.sy);
+        const int x = j - 1;
+        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx);       // block-uniform
+        __syncthreads();
+        act_c = act_n;
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { rw[f] = rc[f]; rc[f] = re[f]; re[f] = re2[f]; rn[f] = rn2[f]; rs[f] = rs2[f]; }
     };
 
     // first row: nothing to emit yet.  Its x-products also stand in for the row before it, which
     // is exactly the clamp-to-self rule when that row lies outside the domain, and is replaced
     // before use otherwise.
-    {
-        double re2[NF2], rn2[NF2], rs2[NF2];
-        const int jn = clampx(j0 + 1);
-        load_row(clampx(j0 + 2), vc, re2);
-        load_row(jn, vn, rn2);
-        load_row(jn, vs, rs2);
-        act_c = load_act(j0);
-        M::phaseA(K, rc, re, rw, rn, rs, Ac);
-        M::put_sy(&lds[j0 & 1][0][t], NT, Ac.sy);
-        Xw = Ac.sx;
-#pragma unroll
-        for (int f = 0; f < NF2; ++f) { rw[f] = rc[f]; rc[f] = re[f]; re[f] = re2[f]; rn[f] = rn2[f]; rs[f] = rs2[f]; }
-        __syncthreads();
-    }
-
-    for (int j = j0 + 1; j <= j1; ++j) {
-        double re2[NF2], rn2[NF2], rs2[NF2];
-        const int jn = clampx(j + 1);
-        unsigned char act_n;
-        if (PREFETCH) {
-            load_row(clampx(j + 2), vc, re2);
-            load_row(jn, vn, rn2);
-            load_row(jn, vs, rs2);
-            act_n = load_act(j);
-        }
-        typename M::PA An;
-        M::phaseA(K, rc, re, rw, rn, rs, An);
-        M::put_sy(&lds[j & 1][0][t], NT, An.sy);
-        if (!PREFETCH) {
-            load_row(clampx(j + 2), vc, re2);
-            load_row(jn, vn, rn2);
-            load_row(jn, vs, rs2);
-            act_n = load_act(j);
-        }
-        const int x = j - 1;
-        if (x >= xs) emit(x, An.sx);               // block-uniform
-        __syncthreads();
-        Xw = Ac.sx;
-        Ac = An;
-        act_c = act_n;
-#pragma unroll
-        for (int f = 0; f < NF2; ++f) { rw[f] = rc[f]; rc[f] = re[f]; re[f] = re2[f]; rn[f] = rn2[f]; rs[f] = rs2[f]; }
+    row(j0, P0, P0, P0, true);
+    P2.sx = P0.sx;
+    int j = j0 + 1, last = 0;
+    for (;;) {
+        if (j > j1) { last = 0; break; }
+        row(j, P1, P0, P2, false); ++j;
+        if (j > j1) { last = 1; break; }
+        row(j, P2, P1, P0, false); ++j;
+        if (j > j1) { last = 2; break; }
+        row(j, P0, P2, P1, false); ++j;
     }
     // last owned row of the domain: its clamped East neighbour is the cell itself
-    if (j1 < xe) emit(xe - 1, Ac.sx);
+    if (j1 < xe) {
+        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx);
+        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx);
+        else emit(xe - 1, P2, P2.sx, P1.sx);
+    }
 }
 
 // correctPrevTime: prev <- pp + 0.5*(c - pp); Density and Temperature in every cell, the
@@ -472,25 +463,28 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
             ev = h->ev_free.back();
             h->ev_free.pop_back();
         }
-        HIP_TRY(hipEventRecord(ev.a, h->stream));
     }
+    // With timing on, the start/stop events are attached to the kernel dispatch itself, so their
+    // difference is the kernel's own begin-to-end time (what a kernel trace reports), free of
+    // queueing gaps.
+    hipEvent_t ea = h->timing ? ev.a : nullptr, eb = h->timing ? ev.b : nullptr;
     const bool fast = (p.flags & CFD_FLAG_FAST_MATH) != 0;
     const uint8_t* act = h->d_active + h->plane;
     if (h->two_d && (p.flags & CFD_FLAG_SIMPLE_KERNEL)) {
         dim3 block(64), grid((p.ny + 63) / 64, p.nx);
         if (fast)
-            hipLaunchKernelGGL(sweep2d_simple<MathFast2>, grid, block, 0, h->stream, h->KF, src, dst, act, p.nx,
-                               p.ny, xlo, xhi);
+            hipExtLaunchKernelGGL(sweep2d_simple<MathFast2>, grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
+                                  act, p.nx, p.ny, xlo, xhi);
         else
-            hipLaunchKernelGGL(sweep2d_simple<MathStrict2>, grid, block, 0, h->stream, h->K, src, dst, act, p.nx,
-                               p.ny, xlo, xhi);
+            hipExtLaunchKernelGGL(sweep2d_simple<MathStrict2>, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst,
+                                  act, p.nx, p.ny, xlo, xhi);
     } else if (h->two_d) {
         const int ch = h->chunk;
 #define LAUNCH_MARCH(M, KK, NT, MINW, PF)                                                          \
     do {                                                                                           \
         dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (p.nx + ch - 1) / ch);                    \
-        hipLaunchKernelGGL((sweep2d_march<M, NT, MINW, PF>), grid, block, 0, h->stream, KK, src,   \
-                           dst, act, p.nx, p.ny, xlo, xhi, ch);                                    \
+        hipExtLaunchKernelGGL((sweep2d_march<M, NT, MINW, PF>), grid, block, 0, h->stream, ea, eb, \
+                              0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch);                     \
     } while (0)
         if (fast) {
             switch (h->variant) {
@@ -515,14 +509,11 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
 #undef LAUNCH_MARCH
     } else {
         dim3 block(64), grid((unsigned)((h->plane + 63) / 64), p.nx);
-        hipLaunchKernelGGL(sweep3d_simple, grid, block, 0, h->stream, h->K, src, dst, act, p.nx, p.ny, p.nz, xlo,
-                           xhi);
+        hipExtLaunchKernelGGL(sweep3d_simple, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst, act, p.nx,
+                              p.ny, p.nz, xlo, xhi);
     }
     HIP_TRY(hipGetLastError());
-    if (h->timing) {
-        HIP_TRY(hipEventRecord(ev.b, h->stream));
-        h->ev_used.push_back(ev);
-    }
+    if (h->timing) h->ev_used.push_back(ev);
     return CFD_OK;
 }
 
@@ -606,7 +597,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
     if (const char* e = getenv("CFD_CHUNK")) { int v = atoi(e); if (v >= 1) h->chunk = v; }
-    h->variant = 2;
+    h->variant = 3;
     if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
     h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;

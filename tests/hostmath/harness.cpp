@@ -112,3 +112,5 @@ extern "C" void hm_sweep2d_fast(int nx, int ny, double dx, double dy, double dz,
             out[F2_DYE][id(x, y)] = act ? o[E2_DYE] : in[F2_DYE][id(x, y)];
         }
 }
+
+extern "C" double hm_half_superbee(double a, double b) { return half_superbee(a, b); }

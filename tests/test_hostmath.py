@@ -69,3 +69,22 @@ def test_sweep3d_math_bit_exact(hm, shape, seed, zero_v):
         for j, i in enumerate(live):
             assert bits_equal(out[j], fb[i]), (sweep, i, float(np.max(np.abs(out[j] - fb[i]))))
         cur = out
+
+
+def test_half_superbee_special_values(hm):
+    """The kernels' branch-free half-limiter against the literal restatement, including zeros,
+    denormals, huge values and mixed signs (the sign of a zero result is not significant)."""
+    from oracle import oracle_a as A
+    hm.hm_half_superbee.restype = ctypes.c_double
+    hm.hm_half_superbee.argtypes = [ctypes.c_double, ctypes.c_double]
+    vals = [0.0, -0.0, 5e-324, -5e-324, 1e-310, 1e-300, 1.0, -1.0, 2.0, 3.0, -3.0, 0.5, 1e300, -1e300,
+            1.7976931348623157e308, 2.5, -2.5, 1e-17]
+    for a in vals:
+        for b in vals:
+            want = 0.5 * A.superbee(a, b)
+            got = hm.hm_half_superbee(a, b)
+            assert got == want, (a, b, got, want)
+    rng = np.random.default_rng(9)
+    for _ in range(3000):
+        a, b = rng.normal(size=2) * 10.0 ** rng.integers(-12, 12)
+        assert hm.hm_half_superbee(a, b) == 0.5 * A.superbee(a, b)
