@@ -492,8 +492,8 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
                 case 2: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, false); break;
                 case 3: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, true); break;
                 case 4: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, false); break;
-                case 5: LAUNCH_MARCH(MathFast2, h->KF, 256, 4, false); break;
-                case 6: LAUNCH_MARCH(MathFast2, h->KF, 128, 4, false); break;
+                case 5: LAUNCH_MARCH(MathFast2, h->KF, 64, 2, true); break;
+                case 6: LAUNCH_MARCH(MathFast2, h->KF, 128, 3, true); break;
                 case 7: LAUNCH_MARCH(MathFast2, h->KF, 256, 3, false); break;
                 default: LAUNCH_MARCH(MathFast2, h->KF, 256, 1, true); break;
             }
