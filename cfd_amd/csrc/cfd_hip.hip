@@ -101,9 +101,9 @@ struct MathStrict2 {
     static constexpr int NSY = 12;
     // stored U, V, Dye of the cell (which = 0, 1, 2)
     __device__ __forceinline__ static double own(const PA& a, int which) { return a.own[which]; }
-    __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* e, const double* w,
+    __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* hx,
                                                   const double* n, const double* s, PA& o) {
-        phaseA2(K, c, e, w, n, s, o);
+        phaseA2(K, c, hx, n, s, o);
     }
     __device__ __forceinline__ static void phaseB(const Consts& K, const PA& C, const SX& XE, const SX& XW,
                                                   const SY& YN, const SY& YS, double* o) {
@@ -130,9 +130,9 @@ struct MathFast2 {
     __device__ __forceinline__ static double own(const PA& a, int which) {
         return which == 0 ? a.phi[E2_U] : (which == 1 ? a.phi[E2_V] : a.phi[E2_DYE]);
     }
-    __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* e, const double* w,
+    __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* hx,
                                                   const double* n, const double* s, PA& o) {
-        phaseA2f(K, c, e, w, n, s, o);
+        phaseA2f(K, c, hx, n, s, o);
     }
     __device__ __forceinline__ static void phaseB(const Consts& K, const PA& C, const SX& XE, const SX& XW,
                                                   const SY& YN, const SY& YS, double* o) {
@@ -184,7 +184,9 @@ __device__ __forceinline__ void phaseA2_at(const typename M::Consts& K, const do
     load5(src, plane5, ny, xw, y, w);
     load5(src, plane5, ny, x, yn, n);
     load5(src, plane5, ny, x, ys, s);
-    M::phaseA(K, c, e, w, n, s, o);
+    double hx[NF2];
+    x_half_slopes2(c, e, w, hx);
+    M::phaseA(K, c, hx, n, s, o);
 }
 
 template <class M>
@@ -361,7 +363,9 @@ sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         load_row(jn, vn, rn2);
         load_row(jn, vs, rs2);
         const unsigned char act_n = load_act(j);
-        M::phaseA(K, rc, re, rw, rn, rs, An);
+        double hx[NF2];
+        x_half_slopes2(rc, re, rw, hx);
+        M::phaseA(K, rc, hx, rn, rs, An);
         M::put_sy(&lds[j & 1][0][t], NT, An.sy);
         const int x = j - 1;
         if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx);       // block-uniform
@@ -386,6 +390,114 @@ sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         row(j, P0, P2, P1, false); ++j;
     }
     // last owned row of the domain: its clamped East neighbour is the cell itself
+    if (j1 < xe) {
+        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx);
+        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx);
+        else emit(xe - 1, P2, P2.sx, P1.sx);
+    }
+}
+
+// Register-lean form of the tiled sweep.  Differences from sweep2d_march:
+//   * a thread reads only its own column from memory (5 loads per row instead of 15); the North /
+//     South neighbours' stored values of the row cross lanes through a second double-buffered LDS
+//     tile.  The two halo lanes have no neighbour on their outer side and use their own value
+//     there: what they publish for their inner neighbour (centre products and East/West face
+//     products) does not depend on their y-slopes, and they store nothing themselves;
+//   * the three live rows of stored values rotate through three register sets together with the
+//     phase-A results (the loop is unrolled by three): the x half-slopes are taken first, which
+//     retires the West row, and the load of row j+2 is issued straight into its registers.
+template <class M, int NT, int MINW>
+__global__ void __launch_bounds__(NT, MINW)
+sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
+               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch) {
+    __shared__ double lds[2][M::NSY][NT];
+    __shared__ double lraw[2][NF2][NT];
+    const int t = threadIdx.x;
+    const int ybase = (int)blockIdx.x * (NT - 2) - 1;      // column of lane 0 before clamping
+    const int y = ybase + t;
+    const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
+    const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
+    // lane that holds column yn / ys (lane l holds column clamp(ybase + l))
+    const int ln = yn - ybase, ls = ys - ybase;
+    const int lnc = ln <= NT - 1 ? ln : t, lsc = ls >= 0 ? ls : t;   // outside the block: own value
+    const bool writer = t >= 1 && t <= NT - 2 && y < ny;
+    const int xs = (int)blockIdx.y * ch;
+    const int xe = xs + ch < nx ? xs + ch : nx;
+    const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
+    const int j1 = xe < xhi ? xe : xhi;
+    const long plane5 = (long)NF2 * ny;
+    const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
+    const unsigned vc = (unsigned)cy * 8u;
+    const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
+    auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
+    auto load_row = [&](int x, unsigned voff, double v[NF2]) {
+        const PlaneRef p(src + (long)x * plane5, pbytes);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) v[f] = p.ld(voff, (unsigned)f * fstride);
+    };
+    auto load_act = [&](int x) { return PlaneRef(active + (long)x * ny, (unsigned)ny).ldb((unsigned)cy); };
+
+    double R0[NF2], R1[NF2], R2[NF2];       // stored values of three consecutive rows (own column)
+    typename M::PA P0, P1, P2;
+    unsigned char act_c = 1;
+
+    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW) {
+        typename M::SY YN, YS;
+        const int tn = t + 1 > NT - 1 ? NT - 1 : t + 1, tsn = t - 1 < 0 ? 0 : t - 1;
+        M::get_sy(&lds[x & 1][0][tn], NT, YN);
+        M::get_sy(&lds[x & 1][0][tsn], NT, YS);
+        double o[5];
+        M::phaseB(K, C, XE, XW, YN, YS, o);
+        const bool act = act_c != 0;
+        const PlaneRef d(dst + (long)x * plane5, pbytes);
+        d.st(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
+        d.st(vst, (unsigned)F2_T * fstride, o[E2_T]);
+        d.st(vst, (unsigned)F2_U * fstride, act ? o[E2_U] : M::own(C, 0));
+        d.st(vst, (unsigned)F2_V * fstride, act ? o[E2_V] : M::own(C, 1));
+        d.st(vst, (unsigned)F2_DYE * fstride, act ? o[E2_DYE] : M::own(C, 2));
+    };
+    // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw[j&1] holds row j of every lane.
+    auto row = [&](int j, double* Rw, const double* Rc, const double* Re, typename M::PA& An,
+                   const typename M::PA& Ac, const typename M::PA& Aw, bool first) {
+        double hx[NF2];
+        x_half_slopes2(Rc, Re, Rw, hx);
+        // Rw is dead: fetch row j+2 into it; also this row's mask
+        load_row(clampx(j + 2), vc, Rw);
+        const unsigned char act_n = load_act(j);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) lraw[(j + 1) & 1][f][t] = Re[f];
+        double rn[NF2], rs[NF2];
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) {
+            rn[f] = lraw[j & 1][f][lnc];
+            rs[f] = lraw[j & 1][f][lsc];
+        }
+        M::phaseA(K, Rc, hx, rn, rs, An);
+        M::put_sy(&lds[j & 1][0][t], NT, An.sy);
+        const int x = j - 1;
+        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx);       // block-uniform
+        __syncthreads();
+        act_c = act_n;
+    };
+
+    load_row(clampx(j0 - 1), vc, R0);
+    load_row(j0, vc, R1);
+    load_row(clampx(j0 + 1), vc, R2);
+#pragma unroll
+    for (int f = 0; f < NF2; ++f) lraw[j0 & 1][f][t] = R1[f];
+    __syncthreads();
+
+    row(j0, R0, R1, R2, P0, P0, P0, true);
+    P2.sx = P0.sx;      // stands in for the row before the first: the clamp-to-self rule
+    int j = j0 + 1, last = 0;
+    for (;;) {
+        if (j > j1) { last = 0; break; }
+        row(j, R1, R2, R0, P1, P0, P2, false); ++j;
+        if (j > j1) { last = 1; break; }
+        row(j, R2, R0, R1, P2, P1, P0, false); ++j;
+        if (j > j1) { last = 2; break; }
+        row(j, R0, R1, R2, P0, P2, P1, false); ++j;
+    }
     if (j1 < xe) {
         if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx);
         else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx);
@@ -480,6 +592,12 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
                                   act, p.nx, p.ny, xlo, xhi);
     } else if (h->two_d) {
         const int ch = h->chunk;
+#define LAUNCH_MARCH2(M, KK, NT, MINW)                                                              \
+    do {                                                                                           \
+        dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (p.nx + ch - 1) / ch);                    \
+        hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW>), grid, block, 0, h->stream, ea, eb, 0, \
+                              KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch);                        \
+    } while (0)
 #define LAUNCH_MARCH(M, KK, NT, MINW, PF)                                                          \
     do {                                                                                           \
         dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (p.nx + ch - 1) / ch);                    \
@@ -487,7 +605,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
                               0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch);                     \
     } while (0)
         if (fast) {
-            switch (h->variant) {
+            switch (h->variant < 0 ? 8 : h->variant) {
                 case 1: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, true); break;
                 case 2: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, false); break;
                 case 3: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, true); break;
@@ -495,18 +613,28 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
                 case 5: LAUNCH_MARCH(MathFast2, h->KF, 64, 2, true); break;
                 case 6: LAUNCH_MARCH(MathFast2, h->KF, 128, 3, true); break;
                 case 7: LAUNCH_MARCH(MathFast2, h->KF, 256, 3, false); break;
+                case 8: LAUNCH_MARCH2(MathFast2, h->KF, 128, 2); break;
+                case 9: LAUNCH_MARCH2(MathFast2, h->KF, 128, 3); break;
+                case 10: LAUNCH_MARCH2(MathFast2, h->KF, 256, 3); break;
+                case 11: LAUNCH_MARCH2(MathFast2, h->KF, 64, 3); break;
+                case 12: LAUNCH_MARCH2(MathFast2, h->KF, 256, 2); break;
                 default: LAUNCH_MARCH(MathFast2, h->KF, 256, 1, true); break;
             }
         } else {
-            switch (h->variant) {
+            switch (h->variant < 0 ? 3 : h->variant) {
                 case 1: LAUNCH_MARCH(MathStrict2, h->K, 256, 2, true); break;
                 case 3: LAUNCH_MARCH(MathStrict2, h->K, 128, 1, true); break;
                 case 4: LAUNCH_MARCH(MathStrict2, h->K, 128, 1, false); break;
                 case 0: LAUNCH_MARCH(MathStrict2, h->K, 256, 1, true); break;
+                case 8: LAUNCH_MARCH2(MathStrict2, h->K, 128, 1); break;
+                case 9: LAUNCH_MARCH2(MathStrict2, h->K, 128, 2); break;
+                case 10: LAUNCH_MARCH2(MathStrict2, h->K, 256, 2); break;
+                case 12: LAUNCH_MARCH2(MathStrict2, h->K, 256, 1); break;
                 default: LAUNCH_MARCH(MathStrict2, h->K, 256, 2, false); break;
             }
         }
 #undef LAUNCH_MARCH
+#undef LAUNCH_MARCH2
     } else {
         dim3 block(64), grid((unsigned)((h->plane + 63) / 64), p.nx);
         hipExtLaunchKernelGGL(sweep3d_simple, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst, act, p.nx,
@@ -597,7 +725,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
     if (const char* e = getenv("CFD_CHUNK")) { int v = atoi(e); if (v >= 1) h->chunk = v; }
-    h->variant = 3;
+    h->variant = -1;
     if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
     h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;

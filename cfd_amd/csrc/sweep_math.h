@@ -176,15 +176,21 @@ struct PhaseA2 {
     ShareY2 sy;
 };
 
-// c,e,w,n,s: the five stored values (F2_* order) of the cell and of its clamped neighbours.
-CFD_HD void phaseA2(const SweepConsts& k, const double c[NF2], const double e[NF2],
-                    const double w[NF2], const double n[NF2], const double s[NF2], PhaseA2& o) {
+// x half-slopes of the five stored values: 0.5*superbee(e - c, c - w).  Split out of phase A so that
+// a kernel can retire the West row's registers (and reuse them for the next load) early.
+CFD_HD void x_half_slopes2(const double c[NF2], const double e[NF2], const double w[NF2], double hx[NF2]) {
+    for (int q = 0; q < NF2; ++q) hx[q] = half_slope(e[q], c[q], w[q]);
+}
+
+// c,n,s: the five stored values (F2_* order) of the cell and of its clamped North/South neighbours;
+// hx: its x half-slopes.
+CFD_HD void phaseA2(const SweepConsts& k, const double c[NF2], const double hx[NF2],
+                    const double n[NF2], const double s[NF2], PhaseA2& o) {
     // limited face values: vc +- 0.5*superbee(up - vc, vc - lo)
     double fE[NF2], fW[NF2], fN[NF2], fS[NF2];
     for (int q = 0; q < NF2; ++q) {
-        const double hx = half_slope(e[q], c[q], w[q]);
         const double hy = half_slope(n[q], c[q], s[q]);
-        fE[q] = c[q] + hx; fW[q] = c[q] - hx;
+        fE[q] = c[q] + hx[q]; fW[q] = c[q] - hx[q];
         fN[q] = c[q] + hy; fS[q] = c[q] - hy;
     }
     const double muC = mu_of(k, c[F2_T]);
@@ -431,13 +437,12 @@ struct PhaseAF {
 // exact zero into 1e-17 changes the next sweep at O(1).  So products are rounded before they are
 // subtracted (no contraction of a*b - c*d); fma is used only to combine already-formed
 // differences with constants, and inside per-cell functions of a single state.
-CFD_HD void phaseA2f(const FastConsts& k, const double c[NF2], const double e[NF2], const double w[NF2],
+CFD_HD void phaseA2f(const FastConsts& k, const double c[NF2], const double hx[NF2],
                      const double n[NF2], const double s[NF2], PhaseAF& o) {
     double fE[NF2], fW[NF2], fN[NF2], fS[NF2];
     for (int q = 0; q < NF2; ++q) {
-        const double hx = half_slope(e[q], c[q], w[q]);
         const double hy = half_slope(n[q], c[q], s[q]);
-        fE[q] = c[q] + hx; fW[q] = c[q] - hx;
+        fE[q] = c[q] + hx[q]; fW[q] = c[q] - hx[q];
         fN[q] = c[q] + hy; fS[q] = c[q] - hy;
     }
     const double muC = mu_fast(k, c[F2_T]);

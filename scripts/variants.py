@@ -5,6 +5,7 @@ from cfd_amd import cases
 from cfd_amd.solver import AdjGraph
 nx = int(os.environ.get("NX", 4096)); ny = int(os.environ.get("NY", 4096))
 params, fields, active = cases.synthetic_2d(nx, ny, seed=1)
+params["dt"] = 1e-7
 for spec in sys.argv[1:]:
     v, ch = spec.split(":")
     os.environ["CFD_VARIANT"] = v; os.environ["CFD_CHUNK"] = ch
@@ -14,9 +15,9 @@ for spec in sys.argv[1:]:
     os.environ["CFD_VARIANT"] = v
     p = dict(params); p["flags"] = fl
     g = AdjGraph(p, fields, active)
-    for _ in range(3): g.sweep(False)
+    for _ in range(30): g.sweep(False)
     g.set_timing(True); g.sweep_timing()
-    for _ in range(10): g.sweep(False)
+    for _ in range(40): g.sweep(False)
     ms, n = g.sweep_timing()
     print("variant %s chunk %s: %.3f ms/sweep  %.2f Gcell/s  %.0f GB/s" % (spec.split(":")[0], ch, ms / n, nx * ny / (ms / n) / 1e6, nx * ny * 81 / (ms / n) / 1e6), flush=True)
     g.close()

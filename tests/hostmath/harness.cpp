@@ -24,7 +24,9 @@ extern "C" void hm_sweep2d(int nx, int ny, double dx, double dy, double dz, doub
                 n[q] = in[q][id(x, cl(y + 1, ny - 1))];
                 s[q] = in[q][id(x, cl(y - 1, ny - 1))];
             }
-            phaseA2(K, c, e, w, n, s, pa[id(x, y)]);
+            double hx[5];
+            x_half_slopes2(c, e, w, hx);
+            phaseA2(K, c, hx, n, s, pa[id(x, y)]);
         }
     for (int x = 0; x < nx; ++x)
         for (int y = 0; y < ny; ++y) {
@@ -97,7 +99,9 @@ extern "C" void hm_sweep2d_fast(int nx, int ny, double dx, double dy, double dz,
                 n[q] = in[q][id(x, cl(y + 1, ny - 1))];
                 s[q] = in[q][id(x, cl(y - 1, ny - 1))];
             }
-            phaseA2f(F, c, e, w, n, s, pa[id(x, y)]);
+            double hx[5];
+            x_half_slopes2(c, e, w, hx);
+            phaseA2f(F, c, hx, n, s, pa[id(x, y)]);
         }
     for (int x = 0; x < nx; ++x)
         for (int y = 0; y < ny; ++y) {

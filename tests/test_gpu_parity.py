@@ -40,9 +40,11 @@ def _assert_slots_bit_equal(g, b, what):
                                                 ((2, 200), 7, True), ((70, 300), 8, False),
                                                 ((37, 254), 9, False), ((33, 255), 10, False),
                                                 ((9, 509), 11, False)])
-@pytest.mark.parametrize("flags,chunk", [(1, 32), (0, 32), (0, 1), (0, 5)])
-def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags, chunk, monkeypatch):
+@pytest.mark.parametrize("flags,chunk,variant", [(1, 32, 3), (0, 32, 3), (0, 1, 3), (0, 5, 3), (0, 32, 8), (0, 1, 8),
+                                                 (0, 4, 12), (0, 7, 0)])
+def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags, chunk, variant, monkeypatch):
     monkeypatch.setenv("CFD_CHUNK", str(chunk))
+    monkeypatch.setenv("CFD_VARIANT", str(variant))
     params, fields, active = small_case(shape[0], shape[1], 1, seed, zero_v)
     g = _gpu_graph(params, fields, active, flags)
     b = _oracle(params, fields, active, pow_mode=1)
