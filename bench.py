@@ -136,6 +136,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = g.graph.sweep_timing(reset=True)
+    fused_ms, fused_launches = g.graph.kernel_timing(1, reset=True)
     g.graph.set_timing(False)
     KERNEL_NAME = g.graph.kernel_name()
     if world > 1:
@@ -163,6 +164,7 @@ def main():
         barrier_s()
         es = time.perf_counter() - ts
         kms, kl = gs.graph.sweep_timing(reset=True)
+        gs.graph.kernel_timing(1, reset=True)
         strict = {"value": cells_per_gpu * SWEEPS_PER_STEP * nstrict / es, "unit": "cell-updates/s",
                   "steps": nstrict, "kernel": gs.graph.kernel_name(), "avg_launch_ms": kms / max(kl, 1),
                   "achieved_GBps": cells_per_gpu * (BYTES_PER_UPDATE_2D if gs.graph.live_fields == 5
@@ -196,7 +198,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(workload),
                      "kernel": "sweep", "bytes_per_cell_update": bytes_per_update,
-                     "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches},
+                     "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches,
+                     "fused_sweep_filter": {"avg_launch_ms": fused_ms / max(fused_launches, 1),
+                                            "launches": fused_launches, "bytes_per_cell": bytes_per_update + 80}},
     }
     if strict is not None:
         out["strict"] = strict

@@ -15,9 +15,9 @@ CFD_FLAG_DEFAULT, CFD_FLAG_SIMPLE_KERNEL, CFD_FLAG_FORCE_3D, CFD_FLAG_FAST_MATH 
 
 # every symbol include/cfd_hip.h declares
 EXPORTS = [
-    "cfd_default_params", "cfd_create", "cfd_destroy", "cfd_step", "cfd_sweep", "cfd_time_filter",
+    "cfd_default_params", "cfd_create", "cfd_destroy", "cfd_step", "cfd_sweep", "cfd_sweep_and_filter", "cfd_time_filter",
     "cfd_total_density", "cfd_read_fields", "cfd_time", "cfd_last_error", "cfd_halo_planes",
-    "cfd_stream", "cfd_set_stream", "cfd_kernel_name", "cfd_sync", "cfd_set_timing", "cfd_sweep_timing", "cfd_live_fields",
+    "cfd_stream", "cfd_set_stream", "cfd_kernel_name", "cfd_sync", "cfd_set_timing", "cfd_sweep_timing", "cfd_kernel_timing", "cfd_live_fields",
 ]
 
 
@@ -67,6 +67,7 @@ def load():
     L.cfd_step.argtypes = [H, ctypes.c_int]
     L.cfd_sweep.argtypes = [H, ctypes.c_int]
     L.cfd_time_filter.argtypes = [H]
+    L.cfd_sweep_and_filter.argtypes = [H]
     L.cfd_total_density.argtypes = [H, ctypes.POINTER(ctypes.c_double)]
     L.cfd_read_fields.argtypes = [H, ctypes.c_int, PP]
     L.cfd_time.argtypes = [H, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
@@ -79,6 +80,8 @@ def load():
     L.cfd_kernel_name.restype = ctypes.c_char_p
     L.cfd_set_timing.argtypes = [H, ctypes.c_int]
     L.cfd_sweep_timing.argtypes = [H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    L.cfd_kernel_timing.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                    ctypes.c_int]
     L.cfd_live_fields.argtypes = [H, ctypes.POINTER(ctypes.c_int)]
     for name in EXPORTS:
         if name not in ("cfd_destroy", "cfd_last_error", "cfd_kernel_name"):

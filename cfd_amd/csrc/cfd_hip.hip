@@ -48,6 +48,7 @@ static int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------
 struct EventPair {
     hipEvent_t a, b;
+    int kind;       // 0 = sweep, 1 = sweep fused with the time filter
 };
 
 struct cfd_handle {
@@ -73,8 +74,8 @@ struct cfd_handle {
     // sweep timing
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
-    double t_ms;
-    int64_t t_launches;
+    double t_ms[2];
+    int64_t t_launches[2];
 };
 
 // field order inside a plane
@@ -406,10 +407,13 @@ sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __re
 //   * the three live rows of stored values rotate through three register sets together with the
 //     phase-A results (the loop is unrolled by three): the x half-slopes are taken first, which
 //     retires the West row, and the load of row j+2 is issued straight into its registers.
-template <class M, int NT, int MINW>
+//   * FILTER: the sweep that ends a step also applies the time filter (correctPrevTime) to the
+//     values it has just computed: prev <- pp + 0.5*(new - pp), so the new slot is not read back.
+template <class M, int NT, int MINW, bool FILTER>
 __global__ void __launch_bounds__(NT, MINW)
 sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
-               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch) {
+               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch,
+               const double* __restrict__ fpp, double* __restrict__ fprev) {
     __shared__ double lds[2][M::NSY][NT];
     __shared__ double lraw[2][NF2][NT];
     const int t = threadIdx.x;
@@ -441,7 +445,16 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     typename M::PA P0, P1, P2;
     unsigned char act_c = 1;
 
-    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW) {
+    // stored values of row x in slot t-2, for the fused filter (issued early, consumed in emit)
+    auto load_pp = [&](int x, double pp[NF2]) {
+        if (FILTER) {
+            const PlaneRef q(fpp + (long)x * plane5, pbytes);
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
+        }
+    };
+    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW,
+                    const double pp[NF2]) {
         typename M::SY YN, YS;
         const int tn = t + 1 > NT - 1 ? NT - 1 : t + 1, tsn = t - 1 < 0 ? 0 : t - 1;
         M::get_sy(&lds[x & 1][0][tn], NT, YN);
@@ -449,20 +462,33 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         double o[5];
         M::phaseB(K, C, XE, XW, YN, YS, o);
         const bool act = act_c != 0;
+        const double nU = act ? o[E2_U] : M::own(C, 0), nV = act ? o[E2_V] : M::own(C, 1),
+                     nD = act ? o[E2_DYE] : M::own(C, 2);
         const PlaneRef d(dst + (long)x * plane5, pbytes);
         d.st(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
         d.st(vst, (unsigned)F2_T * fstride, o[E2_T]);
-        d.st(vst, (unsigned)F2_U * fstride, act ? o[E2_U] : M::own(C, 0));
-        d.st(vst, (unsigned)F2_V * fstride, act ? o[E2_V] : M::own(C, 1));
-        d.st(vst, (unsigned)F2_DYE * fstride, act ? o[E2_DYE] : M::own(C, 2));
+        d.st(vst, (unsigned)F2_U * fstride, nU);
+        d.st(vst, (unsigned)F2_V * fstride, nV);
+        d.st(vst, (unsigned)F2_DYE * fstride, nD);
+        if (FILTER) {
+            // Density and Temperature in every cell; U, V, Dye only where the cell is active
+            const PlaneRef pv(fprev + (long)x * plane5, pbytes);
+            const unsigned vm = act ? vst : 0xFFFFFFF0u;
+            pv.st(vst, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (o[E2_RHO] - pp[F2_RHO])));
+            pv.st(vst, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (o[E2_T] - pp[F2_T])));
+            pv.st(vm, (unsigned)F2_U * fstride, pp[F2_U] + (0.5 * (nU - pp[F2_U])));
+            pv.st(vm, (unsigned)F2_V * fstride, pp[F2_V] + (0.5 * (nV - pp[F2_V])));
+            pv.st(vm, (unsigned)F2_DYE * fstride, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])));
+        }
     };
     // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw[j&1] holds row j of every lane.
     auto row = [&](int j, double* Rw, const double* Rc, const double* Re, typename M::PA& An,
                    const typename M::PA& Ac, const typename M::PA& Aw, bool first) {
-        double hx[NF2];
+        double hx[NF2], pp[NF2];
         x_half_slopes2(Rc, Re, Rw, hx);
         // Rw is dead: fetch row j+2 into it; also this row's mask
         load_row(clampx(j + 2), vc, Rw);
+        if (!first && j - 1 >= xs) load_pp(j - 1, pp);
         const unsigned char act_n = load_act(j);
 #pragma unroll
         for (int f = 0; f < NF2; ++f) lraw[(j + 1) & 1][f][t] = Re[f];
@@ -475,7 +501,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         M::phaseA(K, Rc, hx, rn, rs, An);
         M::put_sy(&lds[j & 1][0][t], NT, An.sy);
         const int x = j - 1;
-        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx);       // block-uniform
+        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, pp);   // block-uniform
         __syncthreads();
         act_c = act_n;
     };
@@ -499,9 +525,11 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         row(j, R0, R1, R2, P0, P2, P1, false); ++j;
     }
     if (j1 < xe) {
-        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx);
-        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx);
-        else emit(xe - 1, P2, P2.sx, P1.sx);
+        double pp[NF2];
+        load_pp(xe - 1, pp);
+        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx, pp);
+        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, pp);
+        else emit(xe - 1, P2, P2.sx, P1.sx, pp);
     }
 }
 
@@ -562,7 +590,11 @@ sum_field_stage2(const double* __restrict__ partial, int n, double* __restrict__
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
+// fpp / fprev non-null: also apply the time filter to the freshly computed values (kernels that
+// support it; *did_fuse tells the caller whether it happened).
+static int launch_sweep(cfd_handle* h, const double* src, double* dst, const double* fpp = nullptr,
+                        double* fprev = nullptr, bool* did_fuse = nullptr) {
+    bool fused = false;
     const cfd_params& p = h->p;
     const int xlo = p.ghost_lo ? -1 : 0;
     const int xhi = p.ghost_hi ? p.nx : p.nx - 1;
@@ -595,8 +627,15 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
 #define LAUNCH_MARCH2(M, KK, NT, MINW)                                                              \
     do {                                                                                           \
         dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (p.nx + ch - 1) / ch);                    \
-        hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW>), grid, block, 0, h->stream, ea, eb, 0, \
-                              KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch);                        \
+        if (fpp)                                                                                   \
+            hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW, true>), grid, block, 0, h->stream,  \
+                                  ea, eb, 0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch, fpp,     \
+                                  fprev);                                                          \
+        else                                                                                       \
+            hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW, false>), grid, block, 0, h->stream, \
+                                  ea, eb, 0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch, fpp,     \
+                                  fprev);                                                          \
+        fused = fpp != nullptr;                                                                    \
     } while (0)
 #define LAUNCH_MARCH(M, KK, NT, MINW, PF)                                                          \
     do {                                                                                           \
@@ -621,7 +660,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
                 default: LAUNCH_MARCH(MathFast2, h->KF, 256, 1, true); break;
             }
         } else {
-            switch (h->variant < 0 ? 3 : h->variant) {
+            switch (h->variant < 0 ? 8 : h->variant) {
                 case 1: LAUNCH_MARCH(MathStrict2, h->K, 256, 2, true); break;
                 case 3: LAUNCH_MARCH(MathStrict2, h->K, 128, 1, true); break;
                 case 4: LAUNCH_MARCH(MathStrict2, h->K, 128, 1, false); break;
@@ -641,7 +680,8 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst) {
                               p.ny, p.nz, xlo, xhi);
     }
     HIP_TRY(hipGetLastError());
-    if (h->timing) h->ev_used.push_back(ev);
+    if (h->timing) { ev.kind = fused ? 1 : 0; h->ev_used.push_back(ev); }
+    if (did_fuse) *did_fuse = fused;
     return CFD_OK;
 }
 
@@ -729,7 +769,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
     h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;
-    h->timing = false; h->t_ms = 0.0; h->t_launches = 0;
+    h->timing = false; h->t_ms[0] = h->t_ms[1] = 0.0; h->t_launches[0] = h->t_launches[1] = 0;
     h->mew.assign(fields[5], fields[5] + n);
 
 #define CREATE_TRY(expr)                                                                       \
@@ -769,6 +809,8 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     return CFD_OK;
 }
 
+static int sweep_in_place(cfd_handle* h, bool with_filter, bool* did_fuse);
+
 int cfd_sweep(cfd_handle* h, int step_time) {
     if (!h) return fail(CFD_E_ARG, "cfd_sweep: null handle");
     HIP_TRY(hipSetDevice(h->device));
@@ -780,11 +822,7 @@ int cfd_sweep(cfd_handle* h, int step_time) {
         h->cmt = nc;
         h->cat += 1;
     } else {
-        int rc = launch_sweep(h, src, slot_base(h, 3));
-        if (rc) return rc;
-        const int t = h->map[h->cmt];
-        h->map[h->cmt] = h->map[3];
-        h->map[3] = t;
+        return sweep_in_place(h, false, nullptr);
     }
     return CFD_OK;
 }
@@ -803,18 +841,46 @@ int cfd_time_filter(cfd_handle* h) {
     return CFD_OK;
 }
 
+// A sweep that does not advance time, optionally fused with the time filter.
+static int sweep_in_place(cfd_handle* h, bool with_filter, bool* did_fuse) {
+    const double* src = slot_base(h, h->cmt);
+    const double* fpp = nullptr;
+    double* fprev = nullptr;
+    if (with_filter && h->cat > 1) {
+        const int tb = (h->cmt + 2) % 3, tc = (tb + 2) % 3;
+        fpp = slot_base(h, tc);
+        fprev = slot_base(h, tb);
+    }
+    int rc = launch_sweep(h, src, slot_base(h, 3), fpp, fprev, did_fuse);
+    if (rc) return rc;
+    const int t = h->map[h->cmt];
+    h->map[h->cmt] = h->map[3];
+    h->map[3] = t;
+    return CFD_OK;
+}
+
+int cfd_sweep_and_filter(cfd_handle* h) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sweep_and_filter: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    bool fused = false;
+    int rc = sweep_in_place(h, true, &fused);
+    if (rc) return rc;
+    return fused ? CFD_OK : cfd_time_filter(h);
+}
+
 int cfd_step(cfd_handle* h, int nsteps) {
     if (!h) return fail(CFD_E_ARG, "cfd_step: null handle");
     if (nsteps < 0) return fail(CFD_E_ARG, "cfd_step: nsteps must be >= 0");
+    HIP_TRY(hipSetDevice(h->device));
     for (int i = 0; i < nsteps; ++i) {
         // The filter after the first and second sweep of a step writes values that the filter
         // after the third overwrites from the same inputs (slot t-2 and the mask do not change,
-        // slot t-1 is not read by any sweep), so only the last of the three is launched.
+        // slot t-1 is not read by any sweep), so only the last of the three is applied -- inside
+        // the third sweep's kernel where that kernel supports it, as its own launch otherwise.
         int rc;
         if ((rc = cfd_sweep(h, 1))) return rc;
         if ((rc = cfd_sweep(h, 0))) return rc;
-        if ((rc = cfd_sweep(h, 0))) return rc;
-        if ((rc = cfd_time_filter(h))) return rc;
+        if ((rc = cfd_sweep_and_filter(h))) return rc;
     }
     return CFD_OK;
 }
@@ -899,6 +965,8 @@ const char* cfd_kernel_name(cfd_handle* h) {
     if (!h->two_d) return "sweep3d_simple";
     const bool fast = (h->p.flags & CFD_FLAG_FAST_MATH) != 0;
     if (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) return fast ? "sweep2d_simple<fast>" : "sweep2d_simple<strict>";
+    const int v = h->variant < 0 ? 8 : h->variant;
+    if (v >= 8) return fast ? "sweep2d_march2<fast>" : "sweep2d_march2<strict>";
     return fast ? "sweep2d_march<fast>" : "sweep2d_march<strict>";
 }
 
@@ -915,22 +983,34 @@ int cfd_set_timing(cfd_handle* h, int enable) {
     return CFD_OK;
 }
 
-int cfd_sweep_timing(cfd_handle* h, double* total_ms, int64_t* launches, int reset) {
-    if (!h) return fail(CFD_E_ARG, "cfd_sweep_timing: null handle");
+static int collect_timing(cfd_handle* h) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto& e : h->ev_used) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
-        h->t_ms += ms;
-        h->t_launches += 1;
+        h->t_ms[e.kind] += ms;
+        h->t_launches[e.kind] += 1;
         h->ev_free.push_back(e);
     }
     h->ev_used.clear();
-    if (total_ms) *total_ms = h->t_ms;
-    if (launches) *launches = h->t_launches;
-    if (reset) { h->t_ms = 0.0; h->t_launches = 0; }
     return CFD_OK;
+}
+
+int cfd_kernel_timing(cfd_handle* h, int kind, double* total_ms, int64_t* launches, int reset) {
+    if (!h) return fail(CFD_E_ARG, "cfd_kernel_timing: null handle");
+    if (kind < 0 || kind > 1) return fail(CFD_E_ARG, "cfd_kernel_timing: kind must be 0 or 1");
+    int rc = collect_timing(h);
+    if (rc) return rc;
+    if (total_ms) *total_ms = h->t_ms[kind];
+    if (launches) *launches = h->t_launches[kind];
+    if (reset) { h->t_ms[kind] = 0.0; h->t_launches[kind] = 0; }
+    return CFD_OK;
+}
+
+int cfd_sweep_timing(cfd_handle* h, double* total_ms, int64_t* launches, int reset) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sweep_timing: null handle");
+    return cfd_kernel_timing(h, 0, total_ms, launches, reset);
 }
 
 int cfd_live_fields(cfd_handle* h, int* nfields) {

@@ -6,7 +6,7 @@ layout keeps all live fields of a plane contiguous, so that halo is ONE message 
 per sweep, sent straight from / received straight into the time slot (no pack kernel).
 
 Per sweep:  exchange ghost planes of the current slot  ->  sweep.
-Per step:   3 x (exchange, sweep), one live filter pass (needs no halo).
+Per step:   3 x (exchange, sweep); the live filter pass needs no halo and is fused into the third sweep.
 Reduction:  local tree sum of Density, then one all-reduce of a single double.
 
 Domain ends keep the reference's clamp-to-self rule (no wrap-around): rank 0 has no low
@@ -148,8 +148,8 @@ class SlabGraph:
         for _ in range(nsteps):
             self.sweep(True)
             self.sweep(False)
-            self.sweep(False)
-            self.time_filter()
+            self.exchange()
+            self.backend.sweep_and_filter()
         return self
 
     def total_density(self):

@@ -104,6 +104,11 @@ class AdjGraph:
         check(self._lib.cfd_time_filter(self._h))
         return self
 
+    def sweep_and_filter(self):
+        """A sweep that does not advance time followed by the time filter (the end of a step)."""
+        check(self._lib.cfd_sweep_and_filter(self._h))
+        return self
+
     def total_density(self):
         v = ctypes.c_double()
         check(self._lib.cfd_total_density(self._h, ctypes.byref(v)))
@@ -120,6 +125,12 @@ class AdjGraph:
         """(total milliseconds, launches) of the sweep kernel since the last reset."""
         ms, n = ctypes.c_double(), ctypes.c_int64()
         check(self._lib.cfd_sweep_timing(self._h, ctypes.byref(ms), ctypes.byref(n), int(bool(reset))))
+        return ms.value, n.value
+
+    def kernel_timing(self, kind, reset=True):
+        """(total milliseconds, launches) of kind 0 = plain sweeps, 1 = sweeps fused with the time filter."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        check(self._lib.cfd_kernel_timing(self._h, int(kind), ctypes.byref(ms), ctypes.byref(n), int(bool(reset))))
         return ms.value, n.value
 
     def halo_planes(self):

@@ -100,7 +100,9 @@ int cfd_create(const cfd_params *p, const double *const fields[CFD_NPROP],
 void cfd_destroy(cfd_handle *h);
 
 /* runSingleStep (src/Main.hs:192-200), nsteps times: three sweeps, the first advancing the
- * time slot, each followed by the time filter. */
+ * time slot, each followed by the time filter.  Only the third filter of a step is live (the
+ * first two are overwritten from the same inputs), so it is applied once, fused into the third
+ * sweep's kernel; results are identical to cfd_sweep x3 + cfd_time_filter x3. */
 int cfd_step(cfd_handle *h, int nsteps);
 
 /* applyDiffEq_adj calcSteps_adj step_time (src/Main.hs:202-226): one forward-Euler sweep of
@@ -111,6 +113,10 @@ int cfd_sweep(cfd_handle *h, int step_time);
 /* correctPrevTime (src/Main.hs:228-258): slot t-1 <- pp + 0.5*(c - pp) with c = slot t,
  * pp = slot t-2; a no-op while currAbsTime <= 1. */
 int cfd_time_filter(cfd_handle *h);
+
+/* applyDiffEq_adj calcSteps_adj False followed by correctPrevTime (the end of a runSingleStep,
+ * src/Main.hs:194-197 with next == 2), in one kernel where the sweep kernel supports it. */
+int cfd_sweep_and_filter(cfd_handle *h);
 
 /* totalDensity (src/Main.hs:269-270): sum of Density over slot currModTime-1 (owned planes).
  * The reference folds sequentially; this is a tree reduction, so the last bits may differ. */
@@ -159,6 +165,10 @@ int cfd_set_timing(cfd_handle *h, int enable);
  * after reading.
  */
 int cfd_sweep_timing(cfd_handle *h, double *total_ms, int64_t *launches, int reset);
+
+/* As cfd_sweep_timing, per kernel kind: 0 = plain sweep launches, 1 = sweeps fused with the time
+ * filter (the last sweep of a cfd_step once currAbsTime > 1). */
+int cfd_kernel_timing(cfd_handle *h, int kind, double *total_ms, int64_t *launches, int reset);
 
 /* Number of live fields the device holds per slot: 5 when nz == 1 and W is identically
  * zero (W then stays exactly zero, so it is neither read nor written), else 6. */

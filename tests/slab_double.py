@@ -56,6 +56,10 @@ class OracleSlabBackend:
     def time_filter(self):
         self.ob.time_filter()
 
+    def sweep_and_filter(self):
+        self.ob.sweep(False)
+        self.ob.time_filter()
+
     def _own(self, a):
         return a[self.gl * self.plane:(self.gl + self.nx) * self.plane]
 

@@ -83,6 +83,22 @@ def test_single_sweep_vs_libm_pow_form():
         assert rel_err(fg[k], f0[k]) <= 1e-13, PROPS[k]
 
 
+@pytest.mark.parametrize("flags", [0, 4])
+def test_fused_filter_equals_separate_filter(flags):
+    """cfd_step (filter fused into the third sweep) against sweep, sweep, sweep, filter launched
+    separately: bit-identical in all three slots, for both arithmetic forms."""
+    params, fields, active = small_case(70, 300, 1, 17)
+    ga = _gpu_graph(params, fields, active, flags)
+    gb = _gpu_graph(params, fields, active, flags)
+    for step in range(4):
+        ga.step(1)
+        gb.sweep(True); gb.sweep(False); gb.sweep(False); gb.time_filter()
+        for rel in range(3):
+            fa, fb = ga.read_fields(rel), gb.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(fa[k], fb[k]), (step, rel, PROPS[k])
+
+
 def test_filter_is_noop_until_second_step():
     params, fields, active = small_case(9, 8, 1, 12)
     g = _gpu_graph(params, fields, active, 1)
