@@ -118,3 +118,21 @@ extern "C" void hm_sweep2d_fast(int nx, int ny, double dx, double dy, double dz,
 }
 
 extern "C" double hm_half_superbee(double a, double b) { return half_superbee(a, b); }
+
+// Brute-force check of div_by against the IEEE division for n pseudo-random numerators (xorshift,
+// magnitudes spread over 2^-60 .. 2^60); returns the number of mismatching bit patterns.
+extern "C" long hm_div_by_mismatches(double h, long n, unsigned long long seed) {
+    const double rh = 1.0 / h;
+    unsigned long long s = seed ? seed : 88172645463325252ull;
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double mant = 1.0 + (double)(s >> 12) * (1.0 / 4503599627370496.0);   // [1,2), 52 random bits
+        const int e = (int)((s >> 3) % 121) - 60;
+        double x = ldexp(mant, e);
+        if (s & 1) x = -x;
+        const double a = x / h, b = div_by(x, h, rh);
+        if (__builtin_memcmp(&a, &b, 8) != 0) ++bad;
+    }
+    return bad;
+}

@@ -88,3 +88,19 @@ def test_half_superbee_special_values(hm):
     for _ in range(3000):
         a, b = rng.normal(size=2) * 10.0 ** rng.integers(-12, 12)
         assert hm.hm_half_superbee(a, b) == 0.5 * A.superbee(a, b)
+
+
+def test_div_by_constant_is_correctly_rounded(hm):
+    """div_by (five fused multiply-adds with a correctly rounded reciprocal) against the IEEE division
+    on 2e7 random numerators for each interval constant of several grids: zero mismatches."""
+    hm.hm_div_by_mismatches.restype = ctypes.c_long
+    hm.hm_div_by_mismatches.argtypes = [ctypes.c_double, ctypes.c_long, ctypes.c_ulonglong]
+    from cfd_amd import cases
+    hs = set()
+    for dx, dy, dz in [(cases.REF_DX, cases.REF_DY, 1.0), (cases.REF_DX, cases.REF_DY, cases.REF_DX),
+                       (0.1, 0.3, 0.7), (1.0 / 3.0, 1e-3, 123.456)]:
+        for ln in (dx, dy, dz):
+            hs.add((0.0 + ln / 2.0) + ln / 2.0)
+            hs.add(2.0 * (((0.0 + ln / 3.0) + ln / 3.0) + ln / 3.0))
+    for i, h in enumerate(sorted(hs)):
+        assert hm.hm_div_by_mismatches(h, 2_000_000, 12345 + i) == 0, h
