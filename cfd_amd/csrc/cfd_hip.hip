@@ -71,6 +71,7 @@ struct cfd_handle {
     FastConsts KF;
     int chunk;              // x-planes per block of the tiled sweep
     int variant;            // tiled-kernel launch shape (tuning knob)
+    bool march3_ok;         // a 3-D x-plane fits 32-bit byte offsets (tiled 3-D kernel usable)
     // sweep timing
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
@@ -213,10 +214,50 @@ sweep2d_simple(typename M::Consts K, const double* __restrict__ src, double* __r
     store5(src, dst, active, plane5, ny, x, y, o);
 }
 
+// Arithmetic policies for the 3-D kernels.
+struct MathStrict3 {
+    using Consts = SweepConsts;
+    using PA = PhaseA3;
+    using SX = ShareX3;
+    using SY = ShareY3;
+    using SZ = ShareZ3;
+    static constexpr const char* name = "strict";
+    // stored U, V, W, Dye of the cell (which = 0..3)
+    __device__ __forceinline__ static double own(const PA& a, int which) { return a.own[which]; }
+    __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double (*h)[NF3], PA& o) {
+        phaseA3_h(K, c, h, o);
+    }
+    __device__ __forceinline__ static void phaseB(const Consts& K, const PA& C, const SX& XP, const SX& XM,
+                                                  const SY& YP, const SY& YM, const SZ& ZP, const SZ& ZM, double* o) {
+        phaseB3(K, C, XP, XM, YP, YM, ZP, ZM, o);
+    }
+};
+
+struct MathFast3 {
+    using Consts = FastConsts;
+    using PA = PhaseA3F;
+    using SX = ShareX3F;
+    using SY = ShareY3F;
+    using SZ = ShareZ3F;
+    static constexpr const char* name = "fast";
+    __device__ __forceinline__ static double own(const PA& a, int which) {
+        return which == 3 ? a.phi[E3_DYE] : a.phi[E3_U + which];
+    }
+    __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double (*h)[NF3], PA& o) {
+        phaseA3f_h(K, c, h, o);
+    }
+    __device__ __forceinline__ static void phaseB(const Consts& K, const PA& C, const SX& XP, const SX& XM,
+                                                  const SY& YP, const SY& YM, const SZ& ZP, const SZ& ZM, double* o) {
+        phaseB3f(K, C, XP, XM, YP, YM, ZP, ZM, o);
+    }
+};
+
 // General 3-D sweep, one thread per cell (lanes along z, then y).  Each thread evaluates phase A
 // for its cell and the parts of its six face neighbours' phase A that it differences.
-__device__ __forceinline__ void phaseA3_at(const SweepConsts& K, const double* __restrict__ src, long plane,
-                                           int ny, int nz, int x, int y, int z, int xlo, int xhi, PhaseA3& o) {
+template <class M>
+__device__ __forceinline__ void phaseA3_at(const typename M::Consts& K, const double* __restrict__ src, long plane,
+                                           int ny, int nz, int x, int y, int z, int xlo, int xhi,
+                                           typename M::PA& o) {
     const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
     const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
     const int zt = z + 1 > nz - 1 ? nz - 1 : z + 1, zb = z - 1 < 0 ? 0 : z - 1;
@@ -231,11 +272,14 @@ __device__ __forceinline__ void phaseA3_at(const SweepConsts& K, const double* _
 #pragma unroll
         for (int s = 0; s < 6; ++s) nb[s][f] = src[o6[s + 1] + (long)f * plane];
     }
-    phaseA3(K, c, nb, o);
+    double h[3][NF3];
+    half_slopes3(c, nb, h);
+    M::phaseA(K, c, h, o);
 }
 
+template <class M>
 __global__ void __launch_bounds__(64)
-sweep3d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict__ dst,
+sweep3d_simple(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
                const uint8_t* __restrict__ active, int nx, int ny, int nz, int xlo, int xhi) {
     const long plane = (long)ny * nz;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -245,19 +289,19 @@ sweep3d_simple(SweepConsts K, const double* __restrict__ src, double* __restrict
     const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
     const int yn = y + 1 > ny - 1 ? ny - 1 : y + 1, ys = y - 1 < 0 ? 0 : y - 1;
     const int zt = z + 1 > nz - 1 ? nz - 1 : z + 1, zb = z - 1 < 0 ? 0 : z - 1;
-    PhaseA3 C, T;
-    ShareX3 XP, XM;
-    ShareY3 YP, YM;
-    ShareZ3 ZP, ZM;
-    phaseA3_at(K, src, plane, ny, nz, x, y, z, xlo, xhi, C);
-    phaseA3_at(K, src, plane, ny, nz, xe, y, z, xlo, xhi, T);  XP = T.sx;
-    phaseA3_at(K, src, plane, ny, nz, xw, y, z, xlo, xhi, T);  XM = T.sx;
-    phaseA3_at(K, src, plane, ny, nz, x, yn, z, xlo, xhi, T);  YP = T.sy;
-    phaseA3_at(K, src, plane, ny, nz, x, ys, z, xlo, xhi, T);  YM = T.sy;
-    phaseA3_at(K, src, plane, ny, nz, x, y, zt, xlo, xhi, T);  ZP = T.sz;
-    phaseA3_at(K, src, plane, ny, nz, x, y, zb, xlo, xhi, T);  ZM = T.sz;
+    typename M::PA C, T;
+    typename M::SX XP, XM;
+    typename M::SY YP, YM;
+    typename M::SZ ZP, ZM;
+    phaseA3_at<M>(K, src, plane, ny, nz, x, y, z, xlo, xhi, C);
+    phaseA3_at<M>(K, src, plane, ny, nz, xe, y, z, xlo, xhi, T);  XP = T.sx;
+    phaseA3_at<M>(K, src, plane, ny, nz, xw, y, z, xlo, xhi, T);  XM = T.sx;
+    phaseA3_at<M>(K, src, plane, ny, nz, x, yn, z, xlo, xhi, T);  YP = T.sy;
+    phaseA3_at<M>(K, src, plane, ny, nz, x, ys, z, xlo, xhi, T);  YM = T.sy;
+    phaseA3_at<M>(K, src, plane, ny, nz, x, y, zt, xlo, xhi, T);  ZP = T.sz;
+    phaseA3_at<M>(K, src, plane, ny, nz, x, y, zb, xlo, xhi, T);  ZM = T.sz;
     double o[NE3];
-    phaseB3(K, C, XP, XM, YP, YM, ZP, ZM, o);
+    M::phaseB(K, C, XP, XM, YP, YM, ZP, ZM, o);
     const bool act = active[(long)x * plane + i] != 0;
     const double* sp = src + (long)x * NF3 * plane + i;
     double* dp = dst + (long)x * NF3 * plane + i;
@@ -533,6 +577,147 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     }
 }
 
+// A struct of doubles to / from a strided LDS column.
+template <class S>
+__device__ __forceinline__ void lds_put(double* __restrict__ l, int st, const S& s) {
+    constexpr int N = sizeof(S) / sizeof(double);
+    double v[N];
+    __builtin_memcpy(v, &s, sizeof(S));
+#pragma unroll
+    for (int i = 0; i < N; ++i) l[i * st] = v[i];
+}
+template <class S>
+__device__ __forceinline__ void lds_get(const double* __restrict__ l, int st, S& s) {
+    constexpr int N = sizeof(S) / sizeof(double);
+    double v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = l[i * st];
+    __builtin_memcpy(&s, v, sizeof(S));
+}
+
+// Tiled 3-D sweep.  A block owns a (TY-2) x (TZ-2) patch of (y, z) columns plus a one-cell halo
+// ring (lanes run along z, the contiguous index) and walks a chunk of x-planes.  As in the 2-D
+// tiled kernel each thread keeps its column's stored values and phase-A results for three
+// consecutive rows in registers, so East/West neighbours never leave the thread.  The North /
+// South / Top / Bottom neighbours' stored values and their y- and z-products cross lanes through
+// LDS (single-buffered, two barriers per row: reads of row j-1's products and row j's stored
+// values, barrier, writes of row j's products and row j+1's stored values, barrier).  Halo
+// threads have no neighbour on their outer side and use their own value there: what they publish
+// towards the patch does not depend on the slopes along that direction, and they store nothing.
+// LDS (dynamic): NF3 + |SY| + |SZ| doubles per thread.
+template <class M, int TY, int TZ, int MINW>
+__global__ void __launch_bounds__(TY * TZ, MINW)
+sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
+              const uint8_t* __restrict__ active, int nx, int ny, int nz, int xlo, int xhi, int ch) {
+    constexpr int NT = TY * TZ;
+    constexpr int NSY = sizeof(typename M::SY) / sizeof(double);
+    extern __shared__ double smem[];
+    double* const lraw = smem;                      // [NF3][NT]
+    double* const lsy = smem + NF3 * NT;            // [NSY][NT]
+    double* const lsz = lsy + NSY * NT;             // [NSZ][NT]
+    const int t = threadIdx.x, tz = t % TZ, ty = t / TZ;
+    const int zbase = (int)blockIdx.x * (TZ - 2) - 1, ybase = (int)blockIdx.y * (TY - 2) - 1;
+    const int y = ybase + ty, z = zbase + tz;
+    const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y), cz = z < 0 ? 0 : (z > nz - 1 ? nz - 1 : z);
+    // thread that holds column (yy, zz); outside the tile: this thread itself
+    auto lane_of = [=](int yy, int zz) {
+        const int ly = yy - ybase, lz = zz - zbase;
+        return (ly >= 0 && ly < TY && lz >= 0 && lz < TZ) ? ly * TZ + lz : t;
+    };
+    const int lN = lane_of(cy + 1 > ny - 1 ? ny - 1 : cy + 1, cz), lS = lane_of(cy - 1 < 0 ? 0 : cy - 1, cz);
+    const int lT = lane_of(cy, cz + 1 > nz - 1 ? nz - 1 : cz + 1), lB = lane_of(cy, cz - 1 < 0 ? 0 : cz - 1);
+    const bool writer = ty >= 1 && ty <= TY - 2 && tz >= 1 && tz <= TZ - 2 && y < ny && z < nz;
+    const int xs = (int)blockIdx.z * ch;
+    const int xe = xs + ch < nx ? xs + ch : nx;
+    const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
+    const int j1 = xe < xhi ? xe : xhi;
+    const long plane = (long)ny * nz, plane6 = (long)NF3 * plane;
+    const unsigned pbytes = (unsigned)(plane6 * 8), fstride = (unsigned)(plane * 8);
+    const unsigned cell = (unsigned)cy * (unsigned)nz + (unsigned)cz;
+    const unsigned vc = cell * 8u;
+    const unsigned vst = writer ? vc : 0xFFFFFFF0u;      // out of range: store dropped
+    auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
+    auto load_row = [&](int x, double v[NF3]) {
+        const PlaneRef p(src + (long)x * plane6, pbytes);
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) v[f] = p.ld(vc, (unsigned)f * fstride);
+    };
+    auto load_act = [&](int x) { return PlaneRef(active + (long)x * plane, (unsigned)plane).ldb(cell); };
+
+    double R0[NF3], R1[NF3], R2[NF3];
+    typename M::PA P0, P1, P2;
+    unsigned char act_c = 1;
+
+    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XP, const typename M::SX& XM) {
+        typename M::SY YP, YM;
+        typename M::SZ ZP, ZM;
+        lds_get(lsy + lN, NT, YP);
+        lds_get(lsy + lS, NT, YM);
+        lds_get(lsz + lT, NT, ZP);
+        lds_get(lsz + lB, NT, ZM);
+        double o[NE3];
+        M::phaseB(K, C, XP, XM, YP, YM, ZP, ZM, o);
+        const bool act = act_c != 0;
+        const PlaneRef d(dst + (long)x * plane6, pbytes);
+        d.st(vst, (unsigned)F3_RHO * fstride, o[E3_RHO]);
+        d.st(vst, (unsigned)F3_T * fstride, o[E3_T]);
+        d.st(vst, (unsigned)F3_U * fstride, act ? o[E3_U] : M::own(C, 0));
+        d.st(vst, (unsigned)F3_V * fstride, act ? o[E3_V] : M::own(C, 1));
+        d.st(vst, (unsigned)F3_W * fstride, act ? o[E3_W] : M::own(C, 2));
+        d.st(vst, (unsigned)F3_DYE * fstride, act ? o[E3_DYE] : M::own(C, 3));
+    };
+    // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw holds row j of every thread, lsy / lsz
+    // the products of row j-1.
+    auto row = [&](int j, double* Rw, const double* Rc, const double* Re, typename M::PA& An,
+                   const typename M::PA& Ac, const typename M::PA& Aw, bool first) {
+        double h[3][NF3];
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) h[0][f] = half_slope(Re[f], Rc[f], Rw[f]);
+        load_row(clampx(j + 2), Rw);        // Rw is dead: fetch row j+2 into it
+        const unsigned char act_n = load_act(j);
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) {
+            h[1][f] = half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS]);
+            h[2][f] = half_slope(lraw[f * NT + lT], Rc[f], lraw[f * NT + lB]);
+        }
+        M::phaseA(K, Rc, h, An);
+        const int x = j - 1;
+        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx);       // block-uniform
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = Re[f];
+        lds_put(lsy + t, NT, An.sy);
+        lds_put(lsz + t, NT, An.sz);
+        __syncthreads();
+        act_c = act_n;
+    };
+
+    load_row(clampx(j0 - 1), R0);
+    load_row(j0, R1);
+    load_row(clampx(j0 + 1), R2);
+#pragma unroll
+    for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = R1[f];
+    __syncthreads();
+
+    row(j0, R0, R1, R2, P0, P0, P0, true);
+    P2.sx = P0.sx;      // stands in for the row before the first: the clamp-to-self rule
+    int j = j0 + 1, last = 0;
+    for (;;) {
+        if (j > j1) { last = 0; break; }
+        row(j, R1, R2, R0, P1, P0, P2, false); ++j;
+        if (j > j1) { last = 1; break; }
+        row(j, R2, R0, R1, P2, P1, P0, false); ++j;
+        if (j > j1) { last = 2; break; }
+        row(j, R0, R1, R2, P0, P2, P1, false); ++j;
+    }
+    // last owned row of the domain: its clamped East neighbour is the cell itself
+    if (j1 < xe) {
+        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx);
+        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx);
+        else emit(xe - 1, P2, P2.sx, P1.sx);
+    }
+}
+
 // correctPrevTime: prev <- pp + 0.5*(c - pp); Density and Temperature in every cell, the
 // other fields only where the cell is active.  Grid: (ceil(plane/256), nf, nx).
 __global__ void __launch_bounds__(256)
@@ -592,6 +777,12 @@ sum_field_stage2(const double* __restrict__ partial, int n, double* __restrict__
 // ------------------------------------------------------------------------------------------
 // fpp / fprev non-null: also apply the time filter to the freshly computed values (kernels that
 // support it; *did_fuse tells the caller whether it happened).
+template <class M>
+static size_t march3_lds_bytes(int nt) {
+    return (size_t)(NF3 + sizeof(typename M::SY) / sizeof(double) + sizeof(typename M::SZ) / sizeof(double)) * nt *
+           sizeof(double);
+}
+
 static int launch_sweep(cfd_handle* h, const double* src, double* dst, const double* fpp = nullptr,
                         double* fprev = nullptr, bool* did_fuse = nullptr) {
     bool fused = false;
@@ -674,10 +865,47 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         }
 #undef LAUNCH_MARCH
 #undef LAUNCH_MARCH2
-    } else {
+    } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok) {
         dim3 block(64), grid((unsigned)((h->plane + 63) / 64), p.nx);
-        hipExtLaunchKernelGGL(sweep3d_simple, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst, act, p.nx,
-                              p.ny, p.nz, xlo, xhi);
+        if (fast)
+            hipExtLaunchKernelGGL(sweep3d_simple<MathFast3>, grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
+                                  act, p.nx, p.ny, p.nz, xlo, xhi);
+        else
+            hipExtLaunchKernelGGL(sweep3d_simple<MathStrict3>, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst,
+                                  act, p.nx, p.ny, p.nz, xlo, xhi);
+    } else {
+        const int ch = h->chunk;
+#define LAUNCH_MARCH3(M, KK, TY, TZ, MINW)                                                          \
+    do {                                                                                           \
+        auto kern = sweep3d_march<M, TY, TZ, MINW>;                                                \
+        const size_t lds = march3_lds_bytes<M>(TY * TZ);                                           \
+        static bool attr_set[64] = {};                                                             \
+        if (lds > 64 * 1024 && !attr_set[h->device & 63]) {                                        \
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                \
+            attr_set[h->device & 63] = true;                                                       \
+        }                                                                                          \
+        dim3 block(TY * TZ), grid((p.nz + TZ - 3) / (TZ - 2), (p.ny + TY - 3) / (TY - 2),          \
+                                  (p.nx + ch - 1) / ch);                                           \
+        hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, KK, src, dst, act,     \
+                              p.nx, p.ny, p.nz, xlo, xhi, ch);                                     \
+    } while (0)
+        if (fast) {
+            switch (h->variant < 0 ? 0 : h->variant) {
+                case 1: LAUNCH_MARCH3(MathFast3, h->KF, 8, 32, 2); break;
+                case 2: LAUNCH_MARCH3(MathFast3, h->KF, 16, 32, 1); break;
+                case 3: LAUNCH_MARCH3(MathFast3, h->KF, 8, 16, 2); break;
+                case 4: LAUNCH_MARCH3(MathFast3, h->KF, 16, 16, 2); break;
+                default: LAUNCH_MARCH3(MathFast3, h->KF, 16, 16, 1); break;
+            }
+        } else {
+            switch (h->variant < 0 ? 0 : h->variant) {
+                case 1: LAUNCH_MARCH3(MathStrict3, h->K, 8, 32, 1); break;
+                case 3: LAUNCH_MARCH3(MathStrict3, h->K, 8, 16, 1); break;
+                default: LAUNCH_MARCH3(MathStrict3, h->K, 16, 16, 1); break;
+            }
+        }
+#undef LAUNCH_MARCH3
     }
     HIP_TRY(hipGetLastError());
     if (h->timing) { ev.kind = fused ? 1 : 0; h->ev_used.push_back(ev); }
@@ -761,7 +989,8 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->nf = h->two_d ? 5 : 6;
     h->slot_elems = (size_t)h->nf * (p->nx + 2) * h->plane;
     h->K = make_consts(p->dx, p->dy, p->dz, p->dt, p->lambda, p->suth, p->R, p->cv, p->k, p->dye_f);
-    h->KF = make_fast_consts(h->K, p->dx, p->dy);
+    h->KF = make_fast_consts(h->K, p->dx, p->dy, p->dz);
+    h->march3_ok = (double)NF3 * (double)h->plane * 8.0 < 4.0e9;
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
     if (const char* e = getenv("CFD_CHUNK")) { int v = atoi(e); if (v >= 1) h->chunk = v; }
@@ -962,8 +1191,12 @@ int cfd_set_stream(cfd_handle* h, void* stream) {
 
 const char* cfd_kernel_name(cfd_handle* h) {
     if (!h) return "";
-    if (!h->two_d) return "sweep3d_simple";
     const bool fast = (h->p.flags & CFD_FLAG_FAST_MATH) != 0;
+    if (!h->two_d) {
+        if ((h->p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok)
+            return fast ? "sweep3d_simple<fast>" : "sweep3d_simple<strict>";
+        return fast ? "sweep3d_march<fast>" : "sweep3d_march<strict>";
+    }
     if (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) return fast ? "sweep2d_simple<fast>" : "sweep2d_simple<strict>";
     const int v = h->variant < 0 ? 8 : h->variant;
     if (v >= 8) return fast ? "sweep2d_march2<fast>" : "sweep2d_march2<strict>";

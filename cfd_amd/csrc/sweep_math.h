@@ -379,19 +379,22 @@ CFD_HD void phaseB2(const SweepConsts& k, const PhaseA2& C, const ShareX2& XE, c
 // form's own rounding noise (<= 1e-13 of the field scale per sweep).
 // ------------------------------------------------------------------------------------------
 struct FastConsts {
-    double rcx, rcy;        // dt/dx, dt/dy                  (flux divergence per unit volume)
-    double kxx, kyy, kxy;   // dt/dx^2, dt/dy^2, dt/(2 dx dy)
-    double kxxm, kyym;      // (2 + m23) * kxx, (2 + m23) * kyy
-    double kxym;            // m23 * kxy
+    double rcx, rcy, rcz;   // dt/dx, dt/dy, dt/dz           (flux divergence per unit volume)
+    double kxx, kyy, kzz;   // dt/dx^2, dt/dy^2, dt/dz^2
+    double kxy, kxz, kyz;   // dt/(2 dx dy), dt/(2 dx dz), dt/(2 dy dz)
+    double kxxm, kyym, kzzm;    // (2 + m23) * kxx, ...
+    double kxym, kxzm, kyzm;    // m23 * kxy, ...
     double lambda, suth, R, cv, rcv, k, dyef;
     double c83h, c83n;
 };
 
-inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy) {
+inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy, double dz = 1.0) {
     FastConsts f;
-    f.rcx = c.dt / dx;  f.rcy = c.dt / dy;
-    f.kxx = c.dt / (dx * dx);  f.kyy = c.dt / (dy * dy);  f.kxy = c.dt / (2.0 * dx * dy);
-    f.kxxm = (2.0 + c.m23) * f.kxx;  f.kyym = (2.0 + c.m23) * f.kyy;  f.kxym = c.m23 * f.kxy;
+    f.rcx = c.dt / dx;  f.rcy = c.dt / dy;  f.rcz = c.dt / dz;
+    f.kxx = c.dt / (dx * dx);  f.kyy = c.dt / (dy * dy);  f.kzz = c.dt / (dz * dz);
+    f.kxy = c.dt / (2.0 * dx * dy);  f.kxz = c.dt / (2.0 * dx * dz);  f.kyz = c.dt / (2.0 * dy * dz);
+    f.kxxm = (2.0 + c.m23) * f.kxx;  f.kyym = (2.0 + c.m23) * f.kyy;  f.kzzm = (2.0 + c.m23) * f.kzz;
+    f.kxym = c.m23 * f.kxy;  f.kxzm = c.m23 * f.kxz;  f.kyzm = c.m23 * f.kyz;
     f.lambda = c.lambda; f.suth = c.suth; f.R = c.R; f.cv = c.cv; f.rcv = 1.0 / c.cv; f.k = c.k; f.dyef = c.dyef;
     f.c83h = c.c83h; f.c83n = c.c83n;
     return f;
@@ -566,22 +569,30 @@ struct ShareZ3 {
 struct PhaseA3 {
     double lhs[NE3];
     double aU[NE3];
+    double own[4];      // stored U, V, W, Dye (kept by inactive cells)
     ShareX3 sx;
     ShareY3 sy;
     ShareZ3 sz;
 };
 
-// c: the cell's six stored values; nb[2*d+s]: those of its clamped neighbour on face (d, s).
-CFD_HD void phaseA3(const SweepConsts& k, const double c[NF3], const double nb[6][NF3], PhaseA3& o) {
+// Limited half-slopes of the six stored values along the three directions; nb[2*d+s]: the values
+// of the clamped neighbour on face (d, s).
+CFD_HD void half_slopes3(const double c[NF3], const double nb[6][NF3], double h[3][NF3]) {
+    for (int d = 0; d < 3; ++d)
+        for (int q = 0; q < NF3; ++q) h[d][q] = half_slope(nb[2 * d][q], c[q], nb[2 * d + 1][q]);
+}
+
+// c: the cell's six stored values; h: their limited half-slopes (half_slopes3).
+CFD_HD void phaseA3_h(const SweepConsts& k, const double c[NF3], const double h[3][NF3], PhaseA3& o) {
     const double A[3] = {k.Ae, k.An, k.At};
     const double dt = k.dt;
     double f[3][2][NF3];          // limited face values
     for (int d = 0; d < 3; ++d)
         for (int q = 0; q < NF3; ++q) {
-            const double h = half_slope(nb[2 * d][q], c[q], nb[2 * d + 1][q]);
-            f[d][0][q] = c[q] + h;
-            f[d][1][q] = c[q] - h;
+            f[d][0][q] = c[q] + h[d][q];
+            f[d][1][q] = c[q] - h[d][q];
         }
+    o.own[0] = c[F3_U]; o.own[1] = c[F3_V]; o.own[2] = c[F3_W]; o.own[3] = c[F3_DYE];
     double mu[3][2], p[3][2];
     for (int d = 0; d < 3; ++d)
         for (int s = 0; s < 2; ++s) {
@@ -691,6 +702,12 @@ CFD_HD void phaseA3(const SweepConsts& k, const double c[NF3], const double nb[6
     }
 }
 
+CFD_HD void phaseA3(const SweepConsts& k, const double c[NF3], const double nb[6][NF3], PhaseA3& o) {
+    double h[3][NF3];
+    half_slopes3(c, nb, h);
+    phaseA3_h(k, c, h, o);
+}
+
 // Right-hand sides and solve.  XP/XM, YP/YM, ZP/ZM: shares of the +/- neighbours in x, y, z (a
 // clamped neighbour is the cell itself).  out[] in E3_* order.
 CFD_HD void phaseB3(const SweepConsts& k, const PhaseA3& C, const ShareX3& XP, const ShareX3& XM,
@@ -771,6 +788,135 @@ CFD_HD void phaseB3(const SweepConsts& k, const PhaseA3& C, const ShareX3& XP, c
 #undef SAMEN
 #undef CROSS
 #undef CROSSN
+}
+
+
+// ------------------------------------------------------------------------------------------
+// General 3-D case, re-associated arithmetic: the increment form of the 2-D fast section with all
+// three directions.  The same exact-cancellation rule applies (products are rounded before they
+// are subtracted).
+// ------------------------------------------------------------------------------------------
+// Products a cell publishes for its +-X, +-Y, +-Z neighbours.  a[c] = mu u_c and g = mu Dye at the
+// centre; p = the combination whose second difference along that direction enters the energy
+// equation; d<F><q> = upper-minus-lower difference over the F faces of mu_f (u_q)_f.
+struct ShareX3F { double a[3], g, p, dYv, dZw, dYu, dZu, qY, qZ; };
+struct ShareY3F { double a[3], g, p, dXv, dXu, dZw, dZv; };
+struct ShareZ3F { double a[3], g, p, dXw, dYw, dXu, dYv, qY; };
+
+struct PhaseA3F {
+    double div[NE3];    // flux divergence per unit volume (E3_* order)
+    double phi[NE3];    // the cell's own rho, U, V, W, T, Dye
+    double rinv;        // 1/rho
+    ShareX3F sx;
+    ShareY3F sy;
+    ShareZ3F sz;
+};
+
+CFD_HD void phaseA3f_h(const FastConsts& k, const double c[NF3], const double h[3][NF3], PhaseA3F& o) {
+    double f[3][2][NF3];
+    for (int d = 0; d < 3; ++d)
+        for (int q = 0; q < NF3; ++q) {
+            f[d][0][q] = c[q] + h[d][q];
+            f[d][1][q] = c[q] - h[d][q];
+        }
+    const double rc[3] = {k.rcx, k.rcy, k.rcz};
+    double div[NE3] = {0, 0, 0, 0, 0, 0};
+    double muf[3][2];
+    double dmu[3][3];       // dmu[d][q] = mu_f (u_q)_f on the upper face of direction d minus the lower face
+    for (int d = 0; d < 3; ++d) {
+        double m[2], p[2];
+        for (int s = 0; s < 2; ++s) {
+            muf[d][s] = mu_fast(k, f[d][s][F3_T]);
+            p[s] = (k.R * f[d][s][F3_T]) * f[d][s][F3_RHO];
+            m[s] = f[d][s][F3_RHO] * f[d][s][F3_U + d];
+        }
+        // flux differences across direction d (products rounded, then subtracted)
+        double dd[NE3];
+        dd[E3_RHO] = m[0] - m[1];
+        for (int cc = 0; cc < 3; ++cc) {
+            dd[E3_U + cc] = m[0] * f[d][0][F3_U + cc] - m[1] * f[d][1][F3_U + cc];
+            if (cc == d) dd[E3_U + cc] = dd[E3_U + cc] + (p[0] - p[1]);
+        }
+        dd[E3_T] = k.cv * (m[0] * f[d][0][F3_T] - m[1] * f[d][1][F3_T])
+                 + (p[0] * f[d][0][F3_U + d] - p[1] * f[d][1][F3_U + d]);
+        dd[E3_DYE] = m[0] * f[d][0][F3_DYE] - m[1] * f[d][1][F3_DYE];
+        for (int e = 0; e < NE3; ++e) div[e] = fma(rc[d], dd[e], div[e]);
+        for (int q = 0; q < 3; ++q) dmu[d][q] = muf[d][0] * f[d][0][F3_U + q] - muf[d][1] * f[d][1][F3_U + q];
+    }
+    for (int e = 0; e < NE3; ++e) o.div[e] = div[e];
+    o.phi[E3_RHO] = c[F3_RHO]; o.phi[E3_U] = c[F3_U]; o.phi[E3_V] = c[F3_V]; o.phi[E3_W] = c[F3_W];
+    o.phi[E3_T] = c[F3_T];     o.phi[E3_DYE] = c[F3_DYE];
+    o.rinv = fast_rcp(c[F3_RHO]);
+
+    const double muC = mu_fast(k, c[F3_T]);
+    double a[3], a2[3];
+    for (int q = 0; q < 3; ++q) { a[q] = muC * c[F3_U + q]; a2[q] = a[q] * a[q]; }
+    const double g = muC * c[F3_DYE], kt = k.k * c[F3_T];
+    // energy combinations: along d the component d carries 8/3 (c83h a_d^2 + c83n a_d), the other
+    // two components carry 1 (a_q^2/2 - a_q)
+    double pc[3];
+    for (int d = 0; d < 3; ++d) {
+        double v = kt + fma(k.c83h, a2[d], k.c83n * a[d]);
+        for (int q = 0; q < 3; ++q)
+            if (q != d) v = v + fma(0.5, a2[q], -a[q]);
+        pc[d] = v;
+    }
+    for (int q = 0; q < 3; ++q) { o.sx.a[q] = a[q]; o.sy.a[q] = a[q]; o.sz.a[q] = a[q]; }
+    o.sx.g = g; o.sy.g = g; o.sz.g = g;
+    o.sx.p = pc[0]; o.sy.p = pc[1]; o.sz.p = pc[2];
+    // paired terms: difference over the faces of direction dout of (mu u_a) u_b - mu u_a - u_b
+    auto paired = [&](int dout, int qa, int qb) {
+        const double up = (muf[dout][0] * f[dout][0][F3_U + qa]) * f[dout][0][F3_U + qb];
+        const double lo = (muf[dout][1] * f[dout][1][F3_U + qa]) * f[dout][1][F3_U + qb];
+        return ((up - lo) - dmu[dout][qa]) - (f[dout][0][F3_U + qb] - f[dout][1][F3_U + qb]);
+    };
+    // the +-X neighbours difference this cell's Y- and Z-face products
+    o.sx.dYv = dmu[1][1];  o.sx.dZw = dmu[2][2];  o.sx.dYu = dmu[1][0];  o.sx.dZu = dmu[2][0];
+    o.sx.qY = paired(1, 0, 1);      // [Mew,U][V] X Y
+    o.sx.qZ = paired(2, 0, 2);      // [Mew,U][W] X Z
+    // the +-Y neighbours: X- and Z-face products
+    o.sy.dXv = dmu[0][1];  o.sy.dXu = dmu[0][0];  o.sy.dZw = dmu[2][2];  o.sy.dZv = dmu[2][1];
+    // the +-Z neighbours: X- and Y-face products
+    o.sz.dXw = dmu[0][2];  o.sz.dYw = dmu[1][2];  o.sz.dXu = dmu[0][0];  o.sz.dYv = dmu[1][1];
+    o.sz.qY = paired(1, 2, 1);      // [Mew,W][V] Z Y
+}
+
+CFD_HD void phaseA3f(const FastConsts& k, const double c[NF3], const double nb[6][NF3], PhaseA3F& o) {
+    double h[3][NF3];
+    half_slopes3(c, nb, h);
+    phaseA3f_h(k, c, h, o);
+}
+
+CFD_HD void phaseB3f(const FastConsts& k, const PhaseA3F& C, const ShareX3F& XP, const ShareX3F& XM,
+                     const ShareY3F& YP, const ShareY3F& YM, const ShareZ3F& ZP, const ShareZ3F& ZM,
+                     double out[NE3]) {
+    // second differences of the centre products along x, y, z
+#define D2X(fld) ((XP.fld + XM.fld) - 2.0 * C.sx.fld)
+#define D2Y(fld) ((YP.fld + YM.fld) - 2.0 * C.sy.fld)
+#define D2Z(fld) ((ZP.fld + ZM.fld) - 2.0 * C.sz.fld)
+    const double rU = fma(k.kxxm, D2X(a[0]), fma(k.kyy, D2Y(a[0]), fma(k.kzz, D2Z(a[0]),
+                      fma(k.kxy, XP.dYv - XM.dYv, fma(k.kxz, XP.dZw - XM.dZw,
+                      fma(k.kxym, YP.dXv - YM.dXv, k.kxzm * (ZP.dXw - ZM.dXw)))))));
+    const double rV = fma(k.kxx, D2X(a[1]), fma(k.kyym, D2Y(a[1]), fma(k.kzz, D2Z(a[1]),
+                      fma(k.kxy, YP.dXu - YM.dXu, fma(k.kyz, YP.dZw - YM.dZw,
+                      fma(k.kxym, XP.dYu - XM.dYu, k.kyzm * (ZP.dYw - ZM.dYw)))))));
+    const double rW = fma(k.kxx, D2X(a[2]), fma(k.kyy, D2Y(a[2]), fma(k.kzzm, D2Z(a[2]),
+                      fma(k.kxz, ZP.dXu - ZM.dXu, fma(k.kyz, ZP.dYv - ZM.dYv,
+                      fma(k.kxzm, XP.dZu - XM.dZu, k.kyzm * (YP.dZv - YM.dZv)))))));
+    const double rT = fma(k.kxx, D2X(p), fma(k.kyy, D2Y(p), fma(k.kzz, D2Z(p),
+                      fma(k.kxy, XP.qY - XM.qY, fma(k.kxz, XP.qZ - XM.qZ, k.kyz * (ZP.qY - ZM.qY))))));
+    const double rD = k.dyef * fma(k.kxx, D2X(g), fma(k.kyy, D2Y(g), k.kzz * D2Z(g)));
+#undef D2X
+#undef D2Y
+#undef D2Z
+    const double gU = C.div[E3_U] - rU, gV = C.div[E3_V] - rV, gW = C.div[E3_W] - rW;
+    const double gT = C.div[E3_T] - rT, gD = C.div[E3_DYE] - rD;
+    out[E3_RHO] = C.phi[E3_RHO] - C.div[E3_RHO];
+    out[E3_U] = C.phi[E3_U] != 0.0 ? fma(-gU, C.rinv, C.phi[E3_U]) : -gU;
+    out[E3_V] = C.phi[E3_V] != 0.0 ? fma(-gV, C.rinv, C.phi[E3_V]) : -gV;
+    out[E3_W] = C.phi[E3_W] != 0.0 ? fma(-gW, C.rinv, C.phi[E3_W]) : -gW;
+    out[E3_T] = C.phi[E3_T] != 0.0 ? fma(-gT, C.rinv * k.rcv, C.phi[E3_T]) : -gT;
+    out[E3_DYE] = C.phi[E3_DYE] != 0.0 ? fma(-gD, C.rinv, C.phi[E3_DYE]) : -gD;
 }
 
 }  // namespace cfd

@@ -1,5 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python -u -m pytest tests/test_gpu_parity.py -x -v --timeout 120 --timeout-method thread -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
+timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py -x -v --timeout 120 --timeout-method thread -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
 tail -25 gpurun_out/gpu_tests.log

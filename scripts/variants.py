@@ -3,8 +3,10 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfd_amd import cases
 from cfd_amd.solver import AdjGraph
-nx = int(os.environ.get("NX", 4096)); ny = int(os.environ.get("NY", 4096))
-params, fields, active = cases.synthetic_2d(nx, ny, seed=1)
+nz = int(os.environ.get("NZ", 1))
+nx = int(os.environ.get("NX", 4096 if nz == 1 else 256)); ny = int(os.environ.get("NY", 4096 if nz == 1 else 256))
+params, fields, active = cases.synthetic_2d(nx, ny, seed=1) if nz == 1 else cases.synthetic_3d(nx, ny, nz, seed=1)
+bpc = 81 if nz == 1 else 97
 params["dt"] = 1e-7
 for spec in sys.argv[1:]:
     v, ch = spec.split(":")
@@ -19,5 +21,5 @@ for spec in sys.argv[1:]:
     g.set_timing(True); g.sweep_timing()
     for _ in range(40): g.sweep(False)
     ms, n = g.sweep_timing()
-    print("variant %s chunk %s: %.3f ms/sweep  %.2f Gcell/s  %.0f GB/s" % (spec.split(":")[0], ch, ms / n, nx * ny / (ms / n) / 1e6, nx * ny * 81 / (ms / n) / 1e6), flush=True)
+    print("variant %s chunk %s: %.3f ms/sweep  %.2f Gcell/s  %.0f GB/s" % (spec.split(":")[0], ch, ms / n, nx * ny * nz / (ms / n) / 1e6, nx * ny * nz * bpc / (ms / n) / 1e6), flush=True)
     g.close()

@@ -136,3 +136,42 @@ extern "C" long hm_div_by_mismatches(double h, long n, unsigned long long seed) 
     }
     return bad;
 }
+
+extern "C" void hm_sweep3d_fast(int nx, int ny, int nz, double dx, double dy, double dz, double dt, double lambda,
+                                double suth, double R, double cv, double k, double dyef,
+                                const double* const in[6], const uint8_t* active, double* const out[6]) {
+    SweepConsts K = make_consts(dx, dy, dz, dt, lambda, suth, R, cv, k, dyef);
+    FastConsts F = make_fast_consts(K, dx, dy, dz);
+    std::vector<PhaseA3F> pa((size_t)nx * ny * nz);
+    auto id = [&](int x, int y, int z) { return ((size_t)x * ny + y) * nz + z; };
+    auto cl = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y)
+            for (int z = 0; z < nz; ++z) {
+                double c[6], nb[6][6];
+                const size_t n6[6] = {id(cl(x + 1, nx - 1), y, z), id(cl(x - 1, nx - 1), y, z),
+                                      id(x, cl(y + 1, ny - 1), z), id(x, cl(y - 1, ny - 1), z),
+                                      id(x, y, cl(z + 1, nz - 1)), id(x, y, cl(z - 1, nz - 1))};
+                for (int q = 0; q < 6; ++q) {
+                    c[q] = in[q][id(x, y, z)];
+                    for (int s = 0; s < 6; ++s) nb[s][q] = in[q][n6[s]];
+                }
+                phaseA3f(F, c, nb, pa[id(x, y, z)]);
+            }
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y)
+            for (int z = 0; z < nz; ++z) {
+                double o[6];
+                const size_t i = id(x, y, z);
+                phaseB3f(F, pa[i], pa[id(cl(x + 1, nx - 1), y, z)].sx, pa[id(cl(x - 1, nx - 1), y, z)].sx,
+                         pa[id(x, cl(y + 1, ny - 1), z)].sy, pa[id(x, cl(y - 1, ny - 1), z)].sy,
+                         pa[id(x, y, cl(z + 1, nz - 1))].sz, pa[id(x, y, cl(z - 1, nz - 1))].sz, o);
+                const bool act = active[i] != 0;
+                out[F3_RHO][i] = o[E3_RHO];
+                out[F3_T][i] = o[E3_T];
+                out[F3_U][i] = act ? o[E3_U] : in[F3_U][i];
+                out[F3_V][i] = act ? o[E3_V] : in[F3_V][i];
+                out[F3_W][i] = act ? o[E3_W] : in[F3_W][i];
+                out[F3_DYE][i] = act ? o[E3_DYE] : in[F3_DYE][i];
+            }
+}

@@ -200,19 +200,26 @@ def test_virtual_rank_slabs_match_single_domain(world, shape):
     assert abs(total - ref.total_density()) <= 1e-12 * abs(total)
 
 
+@pytest.mark.parametrize("kernel,chunk,variant", [(1, 32, -1), (0, 32, -1), (0, 1, -1), (0, 3, -1), (0, 32, 1),
+                                                   (0, 4, 3)])
 @pytest.mark.parametrize("shape,seed,zero_v,flags", [((7, 6, 5), 1, False, 0), ((3, 3, 3), 2, True, 0),
                                                       ((12, 9, 1), 3, False, 2), ((4, 1, 70), 4, False, 0),
                                                       ((1, 1, 1), 5, False, 2), ((9, 20, 13), 6, True, 0),
-                                                      ((20, 3, 1), 7, False, 0)])
-def test_sweeps_bit_exact_3d(shape, seed, zero_v, flags):
-    """General 3-D kernel (also reached with nz == 1 when W != 0 or when forced): bit-exact against
-    Oracle B over sweeps and full steps."""
+                                                      ((20, 3, 1), 7, False, 0), ((5, 31, 30), 8, False, 0),
+                                                      ((40, 15, 29), 9, False, 0)])
+def test_sweeps_bit_exact_3d(shape, seed, zero_v, flags, kernel, chunk, variant, monkeypatch):
+    """General 3-D kernels, per-cell (kernel=1) and tiled in several launch shapes and chunk lengths
+    (also reached with nz == 1 when W != 0 or when forced): bit-exact against Oracle B over sweeps
+    and full steps.  The shapes straddle tile edges (14 and 30 interior columns per tile side)."""
+    monkeypatch.setenv("CFD_CHUNK", str(chunk))
+    monkeypatch.setenv("CFD_VARIANT", str(variant))
     params, fields, active = small_case(shape[0], shape[1], shape[2], seed, zero_v)
     if shape == (20, 3, 1):
         fields[2][:] = np.random.default_rng(1).uniform(-0.2, 0.2, fields[2].size)   # nz == 1 with W != 0
-    g = _gpu_graph(params, fields, active, flags)
+    g = _gpu_graph(params, fields, active, flags | kernel)
     b = _oracle(params, fields, active, pow_mode=1)
-    assert g.live_fields == 6 and g.kernel_name() == "sweep3d_simple"
+    assert g.live_fields == 6
+    assert g.kernel_name() == ("sweep3d_simple<strict>" if kernel else "sweep3d_march<strict>")
     for i, st in enumerate([True, False, False]):
         g.sweep(st)
         b.sweep(st)
@@ -325,6 +332,49 @@ def test_fast_arithmetic_drift_over_steps():
             assert max(errs) <= 1e-12, (n, rel, errs)
         assert abs(gf.total_density() - gs.total_density()) <= 1e-12 * abs(gs.total_density())
     print("fast-vs-strict drift after 90 sweeps:", worst)
+
+
+@pytest.mark.parametrize("kernel_flag", [0, 1])
+@pytest.mark.parametrize("case", ["small", "small_zero_v", "thin", "synthetic"])
+def test_fast_arithmetic_3d_within_1e13_per_sweep(case, kernel_flag):
+    """The 3-D form of the re-associated arithmetic, per-cell and tiled kernel: every sweep, started
+    from the oracle's own state, within 1e-13 of the field scale of Oracle B."""
+    from cfd_amd import cases
+    params, fields, active = {
+        "small": lambda: small_case(9, 20, 13, 6),
+        "small_zero_v": lambda: small_case(7, 6, 5, 2, True),
+        "thin": lambda: small_case(4, 1, 70, 4),
+        "synthetic": lambda: cases.synthetic_3d(40, 36, 33),
+    }[case]()
+    b = _oracle(params, fields, active, pow_mode=1)
+    worst = 0.0
+    for sweep in range(3):
+        cur = b.read_fields(0)
+        g = _gpu_graph(params, cur, active, FAST | kernel_flag)
+        assert g.kernel_name() == ("sweep3d_simple<fast>" if kernel_flag else "sweep3d_march<fast>")
+        g.sweep(True)
+        b.sweep(sweep == 0)
+        errs = field_errors(g.read_fields(0), b.read_fields(0))
+        worst = max(worst, max(errs))
+        for k in range(7):
+            assert errs[k] <= 1e-13, (case, sweep, PROPS[k], errs[k])
+    print("worst per-sweep error (3-D)", case, worst)
+
+
+@pytest.mark.parametrize("flags", [0, FAST])
+def test_tiled_3d_matches_per_cell_3d_bitwise(flags):
+    """Both 3-D kernels evaluate the same expressions: 70 x 45 x 61 (several tiles and chunks, ragged
+    edges), two steps, every slot bit-identical."""
+    from cfd_amd import cases
+    params, fields, active = cases.synthetic_3d(70, 45, 61)
+    ga = _gpu_graph(params, fields, active, flags)
+    gb = _gpu_graph(params, fields, active, flags | 1)
+    ga.step(2)
+    gb.step(2)
+    for rel in range(3):
+        fa, fb = ga.read_fields(rel), gb.read_fields(rel)
+        for k in range(7):
+            assert bits_equal(fa[k], fb[k]), (rel, PROPS[k])
 
 
 def test_fast_tiled_matches_fast_per_cell_bitwise():

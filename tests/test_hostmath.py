@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import bits_equal, oracle_params, small_case
+from helpers import bits_equal, field_errors, oracle_params, small_case
 from oracle import OracleB
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -69,6 +69,53 @@ def test_sweep3d_math_bit_exact(hm, shape, seed, zero_v):
         for j, i in enumerate(live):
             assert bits_equal(out[j], fb[i]), (sweep, i, float(np.max(np.abs(out[j] - fb[i]))))
         cur = out
+
+
+# Re-associated ("fast") arithmetic: not bit-identical by construction.  Bound per sweep, starting
+# each sweep from the oracle's own state: 1e-13 of the field scale (observed: below 1e-14).
+FAST_TOL = 1e-13
+
+
+@pytest.mark.parametrize("shape,seed,zero_v", [((12, 9), 1, False), ((31, 17), 2, True), ((64, 40), 3, False),
+                                                ((1, 1), 4, False), ((2, 5), 5, False)])
+def test_sweep2d_fast_math_close(hm, shape, seed, zero_v):
+    nx, ny = shape
+    params, fields, active = small_case(nx, ny, 1, seed, zero_v)
+    p = oracle_params(params)
+    b = OracleB(p, fields, active, pow_mode=1)
+    live = (0, 1, 3, 4, 6)
+    d = ctypes.c_double
+    for sweep in range(4):
+        cur = [b.read_fields(0)[i].copy() for i in live]
+        b.sweep(sweep == 0)
+        out = [np.empty(nx * ny) for _ in range(5)]
+        hm.hm_sweep2d_fast(nx, ny, d(p["dx"]), d(p["dy"]), d(p["dz"]), d(p["dt"]), d(p["lambda_"]), d(p["suth"]),
+                           d(p["R"]), d(p["cv"]), d(p["k"]), d(p["dye_f"]), _ptrs(cur),
+                           active.ctypes.data_as(ctypes.c_void_p), _ptrs(out))
+        fb = b.read_fields(0)
+        full = [out[0], out[1], fb[2], out[2], out[3], fb[5], out[4]]
+        assert max(field_errors(full, fb)) <= FAST_TOL, (sweep, field_errors(full, fb))
+
+
+@pytest.mark.parametrize("shape,seed,zero_v", [((7, 6, 5), 1, False), ((3, 3, 3), 2, True), ((12, 9, 1), 3, False),
+                                                ((4, 1, 6), 4, False), ((1, 1, 1), 5, False), ((9, 8, 2), 6, True)])
+def test_sweep3d_fast_math_close(hm, shape, seed, zero_v):
+    nx, ny, nz = shape
+    params, fields, active = small_case(nx, ny, nz, seed, zero_v)
+    p = oracle_params(params)
+    b = OracleB(p, fields, active, pow_mode=1)
+    live = (0, 1, 2, 3, 4, 6)
+    d = ctypes.c_double
+    for sweep in range(4):
+        cur = [b.read_fields(0)[i].copy() for i in live]
+        b.sweep(sweep == 0)
+        out = [np.empty(nx * ny * nz) for _ in range(6)]
+        hm.hm_sweep3d_fast(nx, ny, nz, d(p["dx"]), d(p["dy"]), d(p["dz"]), d(p["dt"]), d(p["lambda_"]),
+                           d(p["suth"]), d(p["R"]), d(p["cv"]), d(p["k"]), d(p["dye_f"]), _ptrs(cur),
+                           active.ctypes.data_as(ctypes.c_void_p), _ptrs(out))
+        fb = b.read_fields(0)
+        full = [out[0], out[1], out[2], out[3], out[4], fb[5], out[5]]
+        assert max(field_errors(full, fb)) <= FAST_TOL, (sweep, field_errors(full, fb))
 
 
 def test_half_superbee_special_values(hm):
