@@ -332,6 +332,7 @@ struct PlaneRef {
     __device__ __forceinline__ void st(unsigned voff, unsigned soff, double x) const {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cfd_v2i, x), r, voff, soff, 0);
     }
+
 };
 
 // Tiled sweep ("march"): a block owns NT-2 adjacent columns (lanes run along y, the contiguous
@@ -506,8 +507,9 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         double o[5];
         M::phaseB(K, C, XE, XW, YN, YS, o);
         const bool act = act_c != 0;
-        const double nU = act ? o[E2_U] : M::own(C, 0), nV = act ? o[E2_V] : M::own(C, 1),
-                     nD = act ? o[E2_DYE] : M::own(C, 2);
+        const lane_mask am = mask_of(act);
+        const double nU = select(am, o[E2_U], M::own(C, 0)), nV = select(am, o[E2_V], M::own(C, 1)),
+                     nD = select(am, o[E2_DYE], M::own(C, 2));
         const PlaneRef d(dst + (long)x * plane5, pbytes);
         d.st(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
         d.st(vst, (unsigned)F2_T * fstride, o[E2_T]);
@@ -574,6 +576,154 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx, pp);
         else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, pp);
         else emit(xe - 1, P2, P2.sx, P1.sx, pp);
+    }
+}
+
+// Streaming form of the tiled 2-D sweep (re-associated arithmetic only; an alternative to
+// sweep2d_march2 selected with CFD_VARIANT=20..24, equally fast at 4096 x 4096).  Same tiling and LDS
+// traffic pattern, but a row's phase-A results are turned at once into q, coef and the four
+// pre-scaled neighbour messages (phaseA2s), so the only state a thread carries from row to row is
+// the pending row's q / coef / new Density, the message for the next row's West side, and a ring
+// of RD rows of stored values (RD - 2 rows of prefetch): ~166 registers instead of ~210.
+// Every row is finished unconditionally (stores that do not belong to the chunk are dropped by an
+// out-of-range offset) and the prologue loads are retired before the loop, which keeps the
+// compiler's vector-memory wait counts exact: a row's stores stay in flight under the next row.
+// WCOLS: columns stored per block (NT - 2, or a multiple of 16 for tiles aligned to 128-byte lines).
+//   iteration j:  x half-slopes of row j; issue the load of row j+RD-1 and of the mask of row j+1
+//                 phase A of row j (North/South stored values from lraw[j&1])
+//                 fold the West message (row j-1) into q; publish the North/South messages
+//                 finish row j-1: East message (row j) + North/South messages (lmsg[(j-1)&1]), store
+//                 one barrier
+template <int NT, int MINW, bool FILTER, int RD = 3, int WCOLS = NT - 2>
+__global__ void __launch_bounds__(NT, MINW)
+sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict__ dst,
+               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch,
+               const double* __restrict__ fpp, double* __restrict__ fprev) {
+    __shared__ double lmsg[2][6][NT];
+    __shared__ double lraw[2][NF2][NT];
+    const int t = threadIdx.x;
+    const int ybase = (int)blockIdx.x * WCOLS - 1;         // column of lane 0 before clamping
+    const int y = ybase + t;
+    const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
+    const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
+    const int ln = yn - ybase, ls = ys - ybase;             // lanes holding columns yn / ys
+    const int lnc = ln <= NT - 1 ? ln : t, lsc = ls >= 0 ? ls : t;   // outside the block: own value
+    const bool writer = t >= 1 && t <= WCOLS && y < ny;
+    const int xs = (int)blockIdx.y * ch;
+    const int xe = xs + ch < nx ? xs + ch : nx;
+    const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
+    // Rows j0 .. xe get a phase A; row xe is the East neighbour of the chunk's last row.  At the end
+    // of the domain (xe == xhi + 1) it does not exist: the clamp-to-self rule makes the last row its
+    // own East neighbour, and phase A of "row xe" is then simply evaluated on the clamped row index
+    // (the East message does not depend on the x-slopes, so it comes out as the last row's own).
+    const int j1 = xe;
+    const long plane5 = (long)NF2 * ny;
+    const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
+    const unsigned vc = t <= WCOLS + 1 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // lanes past the tile load nothing
+    const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
+    auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
+    auto load_row = [&](int x, double v[NF2]) {
+        const PlaneRef p(src + (long)x * plane5, pbytes);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) v[f] = p.ld(vc, (unsigned)f * fstride);
+    };
+    auto load_act = [&](int x) { return PlaneRef(active + (long)x * ny, (unsigned)ny).ldb((unsigned)cy); };
+    auto load_pp = [&](int x, double pp[NF2]) {
+        if (FILTER) {
+            const PlaneRef q(fpp + (long)x * plane5, pbytes);
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
+        }
+    };
+
+    double R[RD][NF2];                      // stored values of RD consecutive rows (own column), a ring
+    double pq[4] = {0, 0, 0, 0}, pcoef[4] = {0, 0, 0, 0}, prho = 0.0;   // pending row: q (West folded in), coef, new Density
+    double mwp[3] = {0, 0, 0}, mwpD = 0.0;  // message from the pending row to the row East of it
+    unsigned char act_j;                    // mask of the row whose phase A comes next
+
+    // finish row x: pending values + East message me[] + North/South messages in lmsg[x&1]
+    // vs: this lane's store offset for the row, out of range where nothing is to be stored
+    auto emit = [&](int x, unsigned vs, const double me[4], const double pp[NF2]) {
+        const double (*L)[NT] = lmsg[x & 1];
+        const double nU = stream_finish(pq[S2_U], pcoef[S2_U], me[S2_U], L[0][lnc], L[4][lsc]);
+        const double nV = stream_finish(pq[S2_V], pcoef[S2_V], me[S2_V], L[1][lnc], L[5][lsc]);
+        const double nT = stream_finish(pq[S2_T], pcoef[S2_T], me[S2_T], L[2][lnc], L[2][lsc]);
+        const double nD = stream_finish(pq[S2_DYE], pcoef[S2_DYE], me[S2_DYE], L[3][lnc], L[3][lsc]);
+        const PlaneRef d(dst + (long)x * plane5, pbytes);
+        d.st(vs, (unsigned)F2_RHO * fstride, prho);
+        d.st(vs, (unsigned)F2_T * fstride, nT);
+        d.st(vs, (unsigned)F2_U * fstride, nU);
+        d.st(vs, (unsigned)F2_V * fstride, nV);
+        d.st(vs, (unsigned)F2_DYE * fstride, nD);
+        if (FILTER) {
+            // Density and Temperature in every cell; U, V, Dye only where the cell is active
+            // (coef of U is zero exactly in the cells that keep their values)
+            const PlaneRef pv(fprev + (long)x * plane5, pbytes);
+            const unsigned vm = pcoef[S2_U] != 0.0 ? vs : 0xFFFFFFF0u;
+            pv.st(vs, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (prho - pp[F2_RHO])));
+            pv.st(vs, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (nT - pp[F2_T])));
+            pv.st(vm, (unsigned)F2_U * fstride, pp[F2_U] + (0.5 * (nU - pp[F2_U])));
+            pv.st(vm, (unsigned)F2_V * fstride, pp[F2_V] + (0.5 * (nV - pp[F2_V])));
+            pv.st(vm, (unsigned)F2_DYE * fstride, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])));
+        }
+    };
+    // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw[j&1] holds row j of every lane.
+    auto row = [&](int j, double* Rw, const double* Rc, const double* Re, bool first) {
+        double hx[NF2], pp[NF2];
+        x_half_slopes2(Rc, Re, Rw, hx);
+        load_row(clampx(j + RD - 1), Rw);   // Rw is dead: the row RD-1 ahead goes into it
+        const unsigned char act_n = load_act(clampx(j + 1));
+        // Row j-1 is finished in every iteration, unconditionally, so that the stores sit
+        // on the one straight-line path (the wait counts before the next row's loads are then exact);
+        // for the one row per chunk that belongs to the previous chunk the stores are dropped.
+        const int x = j - 1;
+        load_pp(x < xs ? xs : x, pp);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) lraw[(j + 1) & 1][f][t] = Re[f];
+        double rn[NF2], rs[NF2];
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) {
+            rn[f] = lraw[j & 1][f][lnc];
+            rs[f] = lraw[j & 1][f][lsc];
+        }
+        StreamA2 A;
+        phaseA2s(K, Rc, hx, rn, rs, mask_of(act_j != 0), A);
+        if (first) {    // clamp-to-self on the West side (block-uniform branch, no memory operations inside)
+            mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwpD = A.me[S2_DYE];
+        }
+        stream_west(A.q, A.coef, mwp, mwpD);
+        double (*L)[NT] = lmsg[j & 1];
+        L[0][t] = A.ms[S2_U]; L[1][t] = A.ms[S2_V]; L[2][t] = A.ms[S2_T]; L[3][t] = A.ms[S2_DYE];
+        L[4][t] = A.mn[S2_U]; L[5][t] = A.mn[S2_V];
+        emit(x, x >= xs ? vst : 0xFFFFFFF0u, A.me, pp);
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { pq[f] = A.q[f]; pcoef[f] = A.coef[f]; }
+        prho = A.rho;
+        mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwpD = A.me[S2_DYE];
+        act_j = act_n;
+    };
+
+#pragma unroll
+    for (int u = 0; u < RD; ++u) load_row(clampx(j0 - 1 + u), R[u]);
+    act_j = load_act(j0);
+#pragma unroll
+    for (int f = 0; f < NF2; ++f) lraw[j0 & 1][f][t] = R[1][f];
+    __syncthreads();
+
+    // the ring rotates by one row per iteration; unrolled RD times so that every index is a constant
+    // All prologue loads are retired here, so that the only vector-memory operations pending at the
+    // top of the loop are those of the previous iteration on either way in (exact wait counts: the
+    // stores of a row stay in flight while the next row is computed).
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+    int j = j0;
+    while (j <= j1) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            row(j, R[u % RD], R[(u + 1) % RD], R[(u + 2) % RD], j == j0);
+            ++j;
+            if (j > j1) break;
+        }
     }
 }
 
@@ -657,14 +807,14 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         lds_get(lsz + lB, NT, ZM);
         double o[NE3];
         M::phaseB(K, C, XP, XM, YP, YM, ZP, ZM, o);
-        const bool act = act_c != 0;
+        const lane_mask am = mask_of(act_c != 0);
         const PlaneRef d(dst + (long)x * plane6, pbytes);
         d.st(vst, (unsigned)F3_RHO * fstride, o[E3_RHO]);
         d.st(vst, (unsigned)F3_T * fstride, o[E3_T]);
-        d.st(vst, (unsigned)F3_U * fstride, act ? o[E3_U] : M::own(C, 0));
-        d.st(vst, (unsigned)F3_V * fstride, act ? o[E3_V] : M::own(C, 1));
-        d.st(vst, (unsigned)F3_W * fstride, act ? o[E3_W] : M::own(C, 2));
-        d.st(vst, (unsigned)F3_DYE * fstride, act ? o[E3_DYE] : M::own(C, 3));
+        d.st(vst, (unsigned)F3_U * fstride, select(am, o[E3_U], M::own(C, 0)));
+        d.st(vst, (unsigned)F3_V * fstride, select(am, o[E3_V], M::own(C, 1)));
+        d.st(vst, (unsigned)F3_W * fstride, select(am, o[E3_W], M::own(C, 2)));
+        d.st(vst, (unsigned)F3_DYE * fstride, select(am, o[E3_DYE], M::own(C, 3)));
     };
     // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw holds row j of every thread, lsy / lsz
     // the products of row j-1.
@@ -834,8 +984,26 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         hipExtLaunchKernelGGL((sweep2d_march<M, NT, MINW, PF>), grid, block, 0, h->stream, ea, eb, \
                               0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch);                     \
     } while (0)
+#define LAUNCH_STREAM(NT, MINW, WC)                                                                 \
+    do {                                                                                           \
+        dim3 block(NT), grid((p.ny + WC - 1) / WC, (p.nx + ch - 1) / ch);                          \
+        if (fpp)                                                                                   \
+            hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, true, 3, WC>), grid, block, 0,         \
+                                  h->stream, ea, eb, 0, h->KF, src, dst, act, p.nx, p.ny, xlo,     \
+                                  xhi, ch, fpp, fprev);                                            \
+        else                                                                                       \
+            hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, false, 3, WC>), grid, block, 0,        \
+                                  h->stream, ea, eb, 0, h->KF, src, dst, act, p.nx, p.ny, xlo,     \
+                                  xhi, ch, fpp, fprev);                                            \
+        fused = fpp != nullptr;                                                                    \
+    } while (0)
         if (fast) {
             switch (h->variant < 0 ? 8 : h->variant) {
+                case 20: LAUNCH_STREAM(128, 3, 126); break;
+                case 21: LAUNCH_STREAM(128, 2, 126); break;
+                case 22: LAUNCH_STREAM(64, 3, 62); break;
+                case 23: LAUNCH_STREAM(256, 3, 254); break;
+                case 24: LAUNCH_STREAM(256, 3, 240); break;     // tiles aligned to 128-byte lines
                 case 1: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, true); break;
                 case 2: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, false); break;
                 case 3: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, true); break;
@@ -865,7 +1033,8 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         }
 #undef LAUNCH_MARCH
 #undef LAUNCH_MARCH2
-    } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok) {
+#undef LAUNCH_STREAM
+    } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant < 0)) {
         dim3 block(64), grid((unsigned)((h->plane + 63) / 64), p.nx);
         if (fast)
             hipExtLaunchKernelGGL(sweep3d_simple<MathFast3>, grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
@@ -1193,12 +1362,15 @@ const char* cfd_kernel_name(cfd_handle* h) {
     if (!h) return "";
     const bool fast = (h->p.flags & CFD_FLAG_FAST_MATH) != 0;
     if (!h->two_d) {
-        if ((h->p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok)
+        // strict 3-D: the tiled kernel spills with the strict form's larger product sets and is the
+        // slower one; it runs only when a launch shape is asked for explicitly
+        if ((h->p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant < 0))
             return fast ? "sweep3d_simple<fast>" : "sweep3d_simple<strict>";
         return fast ? "sweep3d_march<fast>" : "sweep3d_march<strict>";
     }
     if (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) return fast ? "sweep2d_simple<fast>" : "sweep2d_simple<strict>";
     const int v = h->variant < 0 ? 8 : h->variant;
+    if (fast && v >= 20 && v <= 24) return "sweep2d_stream<fast>";
     if (v >= 8) return fast ? "sweep2d_march2<fast>" : "sweep2d_march2<strict>";
     return fast ? "sweep2d_march<fast>" : "sweep2d_march<strict>";
 }

@@ -94,21 +94,22 @@ CFD_HD long long to_bits(double x) {
 }
 
 // 0.5 * superbee(a, b), where superbee a b is zero unless a and b are both > 0 or both < 0 and
-// otherwise sign * min(max(|a|,|b|), min(2|a|,2|b|)).  Branch-free:
-//   0.5*min(hi, 2 lo) == min(0.5 hi, lo) exactly (scaling by two is exact);
-//   if either difference is zero then lo == 0 and the minimum is already 0;
-//   "same sign" is an integer test on the two sign bits, applied as a bit mask.
+// otherwise sign * min(max(|a|,|b|), min(2|a|,2|b|)).  Branch-free and select-free:
+//   sb = b with its sign flipped when a is negative, so that "same sign" reads sb > 0;
+//   0.5*min(hi, 2 lo) == min(0.5 hi, lo) exactly (scaling by two is exact), with hi = max(|a|, sb)
+//   and lo = min(|a|, sb); for sb > 0 that is the limiter's magnitude;
+//   for sb <= 0 (opposite signs, or b == 0) lo = sb <= 0 makes the minimum <= 0, and for a == 0
+//   lo <= 0 as well: the outer max(0, .) returns the required zero;
+//   the sign of a is then OR-ed onto the non-negative magnitude.
 // A zero result may carry a sign bit; it is only ever added to / subtracted from the cell value,
 // where +0 and -0 act alike.  (For NaN inputs the reference's getSign calls NaN negative; NaN
 // fields are outside what this code reproduces.)
 CFD_HD double half_superbee(double a, double b) {
-    const double aa = fabs(a), ab = fabs(b);
-    const double hi = fmax(aa, ab), lo = fmin(aa, ab);
-    const double m = fmin(0.5 * hi, lo);
-    const long long sa = to_bits(a), sb = to_bits(b);
-    const long long sign = sa & (long long)0x8000000000000000ull;
-    const long long keep = ~((sa ^ sb) >> 63);          // all ones when the sign bits agree
-    return from_bits((to_bits(m) | sign) & keep);
+    const long long sign = to_bits(a) & (long long)0x8000000000000000ull;
+    const double sb = from_bits(to_bits(b) ^ sign);
+    const double aa = fabs(a);
+    const double m = fmax(0.0, fmin(0.5 * fmax(aa, sb), fmin(aa, sb)));
+    return from_bits(to_bits(m) | sign);
 }
 
 CFD_HD double superbee(double a, double b) { return 2.0 * half_superbee(a, b); }
@@ -134,10 +135,29 @@ CFD_HD double mu_of(const SweepConsts& k, double t) {
     return (k.lambda * (t * sqrt(t))) / (t + k.suth);
 }
 
+// c ? x : y on doubles.  On the device the condition is materialised as a lane mask in a scalar
+// register pair and applied with the three-operand form of the conditional move: measured on
+// gfx950, the two-operand form that reads the mask from VCC issues about three times slower.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned long long lane_mask;
+CFD_HD lane_mask mask_of(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+CFD_HD double select(lane_mask m, double x, double y) {
+    const unsigned long long xb = (unsigned long long)to_bits(x), yb = (unsigned long long)to_bits(y);
+    unsigned lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)yb), "v"((unsigned)xb), "s"(m));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((unsigned)(yb >> 32)), "v"((unsigned)(xb >> 32)), "s"(m));
+    return from_bits((long long)(((unsigned long long)hi << 32) | lo));
+}
+#else
+typedef bool lane_mask;
+CFD_HD lane_mask mask_of(bool c) { return c; }
+CFD_HD double select(lane_mask m, double x, double y) { return m ? x : y; }
+#endif
+
 // F * (1/phi), with the reference's NaN -> 1 substitution.
 CFD_HD double unknown_coeff(double F, double phi) {
     const double u0 = F * (1.0 / phi);
-    return (u0 != u0) ? 1.0 : u0;
+    return select(mask_of(u0 != u0), 1.0, u0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -386,6 +406,10 @@ struct FastConsts {
     double kxym, kxzm, kyzm;    // m23 * kxy, ...
     double lambda, suth, R, cv, rcv, k, dyef;
     double c83h, c83n;
+    // streaming form (2-D): centre coefficients and Dye constants with the Dye factor folded in
+    double cUa, cVb;        // 2 (kxxm + kyy), 2 (kxx + kyym)
+    double kxx2, kyy2;      // 2 kxx, 2 kyy
+    double kxxd, kyyd, cDg; // dyef kxx, dyef kyy, 2 dyef (kxx + kyy)
 };
 
 inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy, double dz = 1.0) {
@@ -397,6 +421,9 @@ inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy, d
     f.kxym = c.m23 * f.kxy;  f.kxzm = c.m23 * f.kxz;  f.kyzm = c.m23 * f.kyz;
     f.lambda = c.lambda; f.suth = c.suth; f.R = c.R; f.cv = c.cv; f.rcv = 1.0 / c.cv; f.k = c.k; f.dyef = c.dyef;
     f.c83h = c.c83h; f.c83n = c.c83n;
+    f.cUa = 2.0 * (f.kxxm + f.kyy);  f.cVb = 2.0 * (f.kxx + f.kyym);
+    f.kxx2 = 2.0 * f.kxx;  f.kyy2 = 2.0 * f.kyy;
+    f.kxxd = c.dyef * f.kxx;  f.kyyd = c.dyef * f.kyy;  f.cDg = 2.0 * (f.kxxd + f.kyyd);
     return f;
 }
 
@@ -520,10 +547,132 @@ CFD_HD void phaseB2f(const FastConsts& k, const PhaseAF& C, const ShareXF& XE, c
     const double gU = C.div[E2_U] - rU, gV = C.div[E2_V] - rV, gT = C.div[E2_T] - rT, gD = C.div[E2_DYE] - rD;
     // increment form; where phi is exactly zero the unknown's coefficient is 1 instead of rho
     out[E2_RHO] = C.phi[E2_RHO] - C.div[E2_RHO];
-    out[E2_U] = C.phi[E2_U] != 0.0 ? fma(-gU, C.rinv, C.phi[E2_U]) : -gU;
-    out[E2_V] = C.phi[E2_V] != 0.0 ? fma(-gV, C.rinv, C.phi[E2_V]) : -gV;
-    out[E2_T] = C.phi[E2_T] != 0.0 ? fma(-gT, C.rinv * k.rcv, C.phi[E2_T]) : -gT;
-    out[E2_DYE] = C.phi[E2_DYE] != 0.0 ? fma(-gD, C.rinv, C.phi[E2_DYE]) : -gD;
+    out[E2_U] = fma(-gU, select(mask_of(C.phi[E2_U] != 0.0), C.rinv, 1.0), C.phi[E2_U]);
+    out[E2_V] = fma(-gV, select(mask_of(C.phi[E2_V] != 0.0), C.rinv, 1.0), C.phi[E2_V]);
+    out[E2_T] = fma(-gT, select(mask_of(C.phi[E2_T] != 0.0), C.rinv * k.rcv, 1.0), C.phi[E2_T]);
+    out[E2_DYE] = fma(-gD, select(mask_of(C.phi[E2_DYE] != 0.0), C.rinv, 1.0), C.phi[E2_DYE]);
+}
+
+// ------------------------------------------------------------------------------------------
+// 2-D case, streaming form of the re-associated arithmetic.  Same mathematics as the section
+// above, arranged so that a marching kernel carries almost nothing from row to row: each cell
+// turns its phase-A results at once into
+//   * q = phi - coef * (div(flux) + centre part of the viscous/conductive terms), and
+//   * one pre-scaled "message" per neighbour: the part of that neighbour's right-hand side this
+//     cell contributes (second-difference term plus or minus the cross-difference term),
+// and a cell's new value is  q + coef * (sum of the four messages addressed to it).
+// coef is 1/rho (1/(rho cv) for Temperature), 1 where phi == 0 (the reference's NaN -> 1 rule) and 0
+// for the fields an inactive cell keeps.  The exact-cancellation rule of the section above holds:
+// a field that is identically zero yields zero messages, zero divergence and an unchanged zero.
+// mu is evaluated with one combined second-order correction of the hardware reciprocal and
+// reciprocal-square-root estimates (relative error ~1e-14; mu only enters terms that are many
+// orders of magnitude below the field scale).
+// ------------------------------------------------------------------------------------------
+enum { S2_U = 0, S2_V, S2_T, S2_DYE };
+
+CFD_HD double mu_stream(const FastConsts& k, double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double z = t + k.suth;
+    const double y = __builtin_amdgcn_rsq(t), r = __builtin_amdgcn_rcp(z);
+    const double g = t * y;                         // ~ sqrt(t), relative error d
+    const double d2 = fma(-g, y, 1.0);              // 2 d
+    const double e = fma(-z, r, 1.0);               // relative error of r
+    const double base = ((k.lambda * t) * g) * r;
+    return fma(base, fma(0.5, d2, e), base);
+#else
+    return (k.lambda * t) * (sqrt(t) / (t + k.suth));
+#endif
+}
+
+struct StreamA2 {
+    double rho;         // new Density (complete)
+    double q[4];        // S2_* order
+    double coef[4];
+    double me[4];       // message to the West neighbour (this cell is its East)
+    double mw[3];       // message to the East neighbour: U, V, T (its Dye entry equals me's)
+    double ms[4];       // message to the South neighbour (this cell is its North)
+    double mn[2];       // message to the North neighbour: U, V (its T and Dye entries equal ms's)
+};
+
+CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[NF2],
+                     const double n[NF2], const double s[NF2], lane_mask act, StreamA2& o) {
+    // ---- x faces
+    double fE[NF2], fW[NF2];
+    for (int q = 0; q < NF2; ++q) { fE[q] = c[q] + hx[q]; fW[q] = c[q] - hx[q]; }
+    const double muE = mu_stream(k, fE[F2_T]), muW = mu_stream(k, fW[F2_T]);
+    const double pE = (k.R * fE[F2_T]) * fE[F2_RHO], pW = (k.R * fW[F2_T]) * fW[F2_RHO];
+    const double mE = fE[F2_RHO] * fE[F2_U], mW = fW[F2_RHO] * fW[F2_U];
+    double div[5];
+    div[E2_RHO] = k.rcx * (mE - mW);
+    div[E2_U] = k.rcx * ((mE * fE[F2_U] - mW * fW[F2_U]) + (pE - pW));
+    div[E2_V] = k.rcx * (mE * fE[F2_V] - mW * fW[F2_V]);
+    div[E2_T] = k.rcx * (k.cv * (mE * fE[F2_T] - mW * fW[F2_T]) + (pE * fE[F2_U] - pW * fW[F2_U]));
+    div[E2_DYE] = k.rcx * (mE * fE[F2_DYE] - mW * fW[F2_DYE]);
+    const double dea = muE * fE[F2_U] - muW * fW[F2_U], deb = muE * fE[F2_V] - muW * fW[F2_V];
+    // ---- y faces
+    double fN[NF2], fS[NF2];
+    for (int q = 0; q < NF2; ++q) {
+        const double hy = half_slope(n[q], c[q], s[q]);
+        fN[q] = c[q] + hy; fS[q] = c[q] - hy;
+    }
+    const double muN = mu_stream(k, fN[F2_T]), muS = mu_stream(k, fS[F2_T]);
+    const double pN = (k.R * fN[F2_T]) * fN[F2_RHO], pS = (k.R * fS[F2_T]) * fS[F2_RHO];
+    const double mN = fN[F2_RHO] * fN[F2_V], mS = fS[F2_RHO] * fS[F2_V];
+    div[E2_RHO] = fma(k.rcy, mN - mS, div[E2_RHO]);
+    div[E2_U] = fma(k.rcy, mN * fN[F2_U] - mS * fS[F2_U], div[E2_U]);
+    div[E2_V] = fma(k.rcy, (mN * fN[F2_V] - mS * fS[F2_V]) + (pN - pS), div[E2_V]);
+    div[E2_T] = fma(k.rcy, k.cv * (mN * fN[F2_T] - mS * fS[F2_T]) + (pN * fN[F2_V] - pS * fS[F2_V]), div[E2_T]);
+    div[E2_DYE] = fma(k.rcy, mN * fN[F2_DYE] - mS * fS[F2_DYE], div[E2_DYE]);
+    const double aN = muN * fN[F2_U], aS = muS * fS[F2_U];
+    const double dna = aN - aS, dnb = muN * fN[F2_V] - muS * fS[F2_V];
+    const double qq = ((aN * fN[F2_V] - aS * fS[F2_V]) - dna) - (fN[F2_V] - fS[F2_V]);
+    // ---- centre products
+    const double muC = mu_stream(k, c[F2_T]);
+    const double a = muC * c[F2_U], b = muC * c[F2_V], g = muC * c[F2_DYE];
+    const double a2 = a * a, b2 = b * b, kt = k.k * c[F2_T];
+    const double px = (kt + fma(k.c83h, a2, k.c83n * a)) + fma(0.5, b2, -b);
+    const double py = (kt + fma(k.c83h, b2, k.c83n * b)) + fma(0.5, a2, -a);
+    // ---- messages
+    const double sxU = k.kxxm * a, txU = k.kxy * dnb;
+    const double sxV = k.kxx * b, txV = k.kxym * dna;
+    const double sxT = k.kxx * px, txT = k.kxy * qq;
+    o.me[S2_U] = sxU + txU;  o.mw[S2_U] = sxU - txU;
+    o.me[S2_V] = sxV + txV;  o.mw[S2_V] = sxV - txV;
+    o.me[S2_T] = sxT + txT;  o.mw[S2_T] = sxT - txT;
+    o.me[S2_DYE] = k.kxxd * g;
+    const double syU = k.kyy * a, tyU = k.kxym * deb;
+    const double syV = k.kyym * b, tyV = k.kxy * dea;
+    o.ms[S2_U] = syU + tyU;  o.mn[S2_U] = syU - tyU;
+    o.ms[S2_V] = syV + tyV;  o.mn[S2_V] = syV - tyV;
+    o.ms[S2_T] = k.kyy * py;
+    o.ms[S2_DYE] = k.kyyd * g;
+    // ---- the cell's own part
+    const double gU = fma(k.cUa, a, div[E2_U]), gV = fma(k.cVb, b, div[E2_V]);
+    const double gT = fma(k.kxx2, px, fma(k.kyy2, py, div[E2_T])), gD = fma(k.cDg, g, div[E2_DYE]);
+    const double rinv = fast_rcp(c[F2_RHO]);
+    const double keep = select(act, 1.0, 0.0);
+    o.coef[S2_U] = select(act & mask_of(c[F2_U] != 0.0), rinv, keep);
+    o.coef[S2_V] = select(act & mask_of(c[F2_V] != 0.0), rinv, keep);
+    o.coef[S2_T] = select(mask_of(c[F2_T] != 0.0), rinv * k.rcv, 1.0);
+    o.coef[S2_DYE] = select(act & mask_of(c[F2_DYE] != 0.0), rinv, keep);
+    o.q[S2_U] = fma(-o.coef[S2_U], gU, c[F2_U]);
+    o.q[S2_V] = fma(-o.coef[S2_V], gV, c[F2_V]);
+    o.q[S2_T] = fma(-o.coef[S2_T], gT, c[F2_T]);
+    o.q[S2_DYE] = fma(-o.coef[S2_DYE], gD, c[F2_DYE]);
+    o.rho = c[F2_RHO] - div[E2_RHO];
+}
+
+// q += coef * (message from the West neighbour); mwD: that message's Dye entry
+CFD_HD void stream_west(double q[4], const double coef[4], const double mw[3], double mwD) {
+    q[S2_U] = fma(coef[S2_U], mw[S2_U], q[S2_U]);
+    q[S2_V] = fma(coef[S2_V], mw[S2_V], q[S2_V]);
+    q[S2_T] = fma(coef[S2_T], mw[S2_T], q[S2_T]);
+    q[S2_DYE] = fma(coef[S2_DYE], mwD, q[S2_DYE]);
+}
+
+// new value of one field: q (West already folded in) plus the East, North and South messages
+CFD_HD double stream_finish(double q, double coef, double from_e, double from_n, double from_s) {
+    return fma(coef, (from_e + from_n) + from_s, q);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -912,11 +1061,11 @@ CFD_HD void phaseB3f(const FastConsts& k, const PhaseA3F& C, const ShareX3F& XP,
     const double gU = C.div[E3_U] - rU, gV = C.div[E3_V] - rV, gW = C.div[E3_W] - rW;
     const double gT = C.div[E3_T] - rT, gD = C.div[E3_DYE] - rD;
     out[E3_RHO] = C.phi[E3_RHO] - C.div[E3_RHO];
-    out[E3_U] = C.phi[E3_U] != 0.0 ? fma(-gU, C.rinv, C.phi[E3_U]) : -gU;
-    out[E3_V] = C.phi[E3_V] != 0.0 ? fma(-gV, C.rinv, C.phi[E3_V]) : -gV;
-    out[E3_W] = C.phi[E3_W] != 0.0 ? fma(-gW, C.rinv, C.phi[E3_W]) : -gW;
-    out[E3_T] = C.phi[E3_T] != 0.0 ? fma(-gT, C.rinv * k.rcv, C.phi[E3_T]) : -gT;
-    out[E3_DYE] = C.phi[E3_DYE] != 0.0 ? fma(-gD, C.rinv, C.phi[E3_DYE]) : -gD;
+    out[E3_U] = fma(-gU, select(mask_of(C.phi[E3_U] != 0.0), C.rinv, 1.0), C.phi[E3_U]);
+    out[E3_V] = fma(-gV, select(mask_of(C.phi[E3_V] != 0.0), C.rinv, 1.0), C.phi[E3_V]);
+    out[E3_W] = fma(-gW, select(mask_of(C.phi[E3_W] != 0.0), C.rinv, 1.0), C.phi[E3_W]);
+    out[E3_T] = fma(-gT, select(mask_of(C.phi[E3_T] != 0.0), C.rinv * k.rcv, 1.0), C.phi[E3_T]);
+    out[E3_DYE] = fma(-gD, select(mask_of(C.phi[E3_DYE] != 0.0), C.rinv, 1.0), C.phi[E3_DYE]);
 }
 
 }  // namespace cfd

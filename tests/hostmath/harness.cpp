@@ -175,3 +175,42 @@ extern "C" void hm_sweep3d_fast(int nx, int ny, int nz, double dx, double dy, do
                 out[F3_DYE][i] = act ? o[E3_DYE] : in[F3_DYE][i];
             }
 }
+
+extern "C" void hm_sweep2d_stream(int nx, int ny, double dx, double dy, double dz, double dt, double lambda,
+                                  double suth, double R, double cv, double k, double dyef,
+                                  const double* const in[5], const uint8_t* active, double* const out[5]) {
+    SweepConsts K = make_consts(dx, dy, dz, dt, lambda, suth, R, cv, k, dyef);
+    FastConsts F = make_fast_consts(K, dx, dy);
+    std::vector<StreamA2> pa((size_t)nx * ny);
+    auto id = [&](int x, int y) { return (size_t)x * ny + y; };
+    auto cl = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y) {
+            double c[5], e[5], w[5], n[5], s[5];
+            for (int q = 0; q < 5; ++q) {
+                c[q] = in[q][id(x, y)];
+                e[q] = in[q][id(cl(x + 1, nx - 1), y)];
+                w[q] = in[q][id(cl(x - 1, nx - 1), y)];
+                n[q] = in[q][id(x, cl(y + 1, ny - 1))];
+                s[q] = in[q][id(x, cl(y - 1, ny - 1))];
+            }
+            double hx[5];
+            x_half_slopes2(c, e, w, hx);
+            phaseA2s(F, c, hx, n, s, active[id(x, y)] != 0, pa[id(x, y)]);
+        }
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y) {
+            const StreamA2& C = pa[id(x, y)];
+            const StreamA2& E = pa[id(cl(x + 1, nx - 1), y)];
+            const StreamA2& W = pa[id(cl(x - 1, nx - 1), y)];
+            const StreamA2& N = pa[id(x, cl(y + 1, ny - 1))];
+            const StreamA2& S = pa[id(x, cl(y - 1, ny - 1))];
+            double q[4] = {C.q[0], C.q[1], C.q[2], C.q[3]};
+            stream_west(q, C.coef, W.mw, W.me[S2_DYE]);
+            out[F2_RHO][id(x, y)] = C.rho;
+            out[F2_U][id(x, y)] = stream_finish(q[S2_U], C.coef[S2_U], E.me[S2_U], N.ms[S2_U], S.mn[S2_U]);
+            out[F2_V][id(x, y)] = stream_finish(q[S2_V], C.coef[S2_V], E.me[S2_V], N.ms[S2_V], S.mn[S2_V]);
+            out[F2_T][id(x, y)] = stream_finish(q[S2_T], C.coef[S2_T], E.me[S2_T], N.ms[S2_T], S.ms[S2_T]);
+            out[F2_DYE][id(x, y)] = stream_finish(q[S2_DYE], C.coef[S2_DYE], E.me[S2_DYE], N.ms[S2_DYE], S.ms[S2_DYE]);
+        }
+}

@@ -200,7 +200,7 @@ def test_virtual_rank_slabs_match_single_domain(world, shape):
     assert abs(total - ref.total_density()) <= 1e-12 * abs(total)
 
 
-@pytest.mark.parametrize("kernel,chunk,variant", [(1, 32, -1), (0, 32, -1), (0, 1, -1), (0, 3, -1), (0, 32, 1),
+@pytest.mark.parametrize("kernel,chunk,variant", [(1, 32, -1), (0, 32, 0), (0, 1, 0), (0, 3, 0), (0, 32, 1),
                                                    (0, 4, 3)])
 @pytest.mark.parametrize("shape,seed,zero_v,flags", [((7, 6, 5), 1, False, 0), ((3, 3, 3), 2, True, 0),
                                                       ((12, 9, 1), 3, False, 2), ((4, 1, 70), 4, False, 0),
@@ -362,15 +362,52 @@ def test_fast_arithmetic_3d_within_1e13_per_sweep(case, kernel_flag):
 
 
 @pytest.mark.parametrize("flags", [0, FAST])
-def test_tiled_3d_matches_per_cell_3d_bitwise(flags):
+def test_tiled_3d_matches_per_cell_3d_bitwise(flags, monkeypatch):
     """Both 3-D kernels evaluate the same expressions: 70 x 45 x 61 (several tiles and chunks, ragged
     edges), two steps, every slot bit-identical."""
     from cfd_amd import cases
+    monkeypatch.setenv("CFD_VARIANT", "0")      # the tiled kernel also for strict arithmetic
     params, fields, active = cases.synthetic_3d(70, 45, 61)
     ga = _gpu_graph(params, fields, active, flags)
     gb = _gpu_graph(params, fields, active, flags | 1)
     ga.step(2)
     gb.step(2)
+    for rel in range(3):
+        fa, fb = ga.read_fields(rel), gb.read_fields(rel)
+        for k in range(7):
+            assert bits_equal(fa[k], fb[k]), (rel, PROPS[k])
+
+
+@pytest.mark.parametrize("variant,chunk", [(20, 32), (21, 5), (22, 1), (23, 32), (24, 7)])
+@pytest.mark.parametrize("case", ["small", "small_zero_v", "shipped", "cavity"])
+def test_streaming_kernel_within_1e13_per_sweep(case, variant, chunk, monkeypatch):
+    """The streaming form of the tiled 2-D kernel (messages instead of shared products) in its launch
+    shapes: every sweep, started from the oracle's own state, within 1e-13 of the field scale of
+    Oracle B; and a fused last sweep equals sweep + separate filter bit for bit."""
+    from cfd_amd import cases
+    monkeypatch.setenv("CFD_VARIANT", str(variant))
+    monkeypatch.setenv("CFD_CHUNK", str(chunk))
+    params, fields, active = {
+        "small": lambda: small_case(40, 33, 1, 13),
+        "small_zero_v": lambda: small_case(31, 17, 1, 2, True),
+        "shipped": cases.reference_case,
+        "cavity": lambda: cases.cavity_2d(64, 64),
+    }[case]()
+    b = _oracle(params, fields, active, pow_mode=1)
+    for sweep in range(3):
+        cur = b.read_fields(0)
+        g = _gpu_graph(params, cur, active, FAST)
+        assert g.kernel_name() == "sweep2d_stream<fast>"
+        g.sweep(True)
+        b.sweep(sweep == 0)
+        errs = field_errors(g.read_fields(0), b.read_fields(0))
+        for k in range(7):
+            assert errs[k] <= 1e-13, (case, sweep, PROPS[k], errs[k])
+    ga = _gpu_graph(params, fields, active, FAST)
+    gb = _gpu_graph(params, fields, active, FAST)
+    for _ in range(2):
+        ga.sweep(True); ga.sweep(False); ga.sweep_and_filter()
+        gb.sweep(True); gb.sweep(False); gb.sweep(False); gb.time_filter()
     for rel in range(3):
         fa, fb = ga.read_fields(rel), gb.read_fields(rel)
         for k in range(7):

@@ -78,7 +78,8 @@ FAST_TOL = 1e-13
 
 @pytest.mark.parametrize("shape,seed,zero_v", [((12, 9), 1, False), ((31, 17), 2, True), ((64, 40), 3, False),
                                                 ((1, 1), 4, False), ((2, 5), 5, False)])
-def test_sweep2d_fast_math_close(hm, shape, seed, zero_v):
+@pytest.mark.parametrize("entry", ["hm_sweep2d_fast", "hm_sweep2d_stream"])
+def test_sweep2d_fast_math_close(hm, shape, seed, zero_v, entry):
     nx, ny = shape
     params, fields, active = small_case(nx, ny, 1, seed, zero_v)
     p = oracle_params(params)
@@ -89,7 +90,7 @@ def test_sweep2d_fast_math_close(hm, shape, seed, zero_v):
         cur = [b.read_fields(0)[i].copy() for i in live]
         b.sweep(sweep == 0)
         out = [np.empty(nx * ny) for _ in range(5)]
-        hm.hm_sweep2d_fast(nx, ny, d(p["dx"]), d(p["dy"]), d(p["dz"]), d(p["dt"]), d(p["lambda_"]), d(p["suth"]),
+        getattr(hm, entry)(nx, ny, d(p["dx"]), d(p["dy"]), d(p["dz"]), d(p["dt"]), d(p["lambda_"]), d(p["suth"]),
                            d(p["R"]), d(p["cv"]), d(p["k"]), d(p["dye_f"]), _ptrs(cur),
                            active.ctypes.data_as(ctypes.c_void_p), _ptrs(out))
         fb = b.read_fields(0)
