@@ -868,6 +868,129 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     }
 }
 
+// Streaming form of the tiled 3-D sweep (re-associated arithmetic only): sweep3d_march's tiling with
+// phaseA3s' messages instead of shared products, the row-to-row state of sweep2d_stream (pending q /
+// coef / Density, West message, ring of RD stored rows) and its unconditional row finishing.
+// LDS (dynamic, single-buffered, two barriers per row): 6 stored values + 8 y-message + 9 z-message
+// doubles per thread.
+template <int TY, int TZ, int MINW, int RD = 3>
+__global__ void __launch_bounds__(TY * TZ, MINW)
+sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict__ dst,
+               const uint8_t* __restrict__ active, int nx, int ny, int nz, int xlo, int xhi, int ch) {
+    constexpr int NT = TY * TZ;
+    extern __shared__ double smem[];
+    double* const lraw = smem;                  // [NF3][NT]
+    double* const lmy = smem + NF3 * NT;        // [8][NT]: ms[0..4], mn[0..2]
+    double* const lmz = lmy + 8 * NT;           // [9][NT]: mb[0..4], mt[0..3]
+    const int t = threadIdx.x, tz = t % TZ, ty = t / TZ;
+    const int zbase = (int)blockIdx.x * (TZ - 2) - 1, ybase = (int)blockIdx.y * (TY - 2) - 1;
+    const int y = ybase + ty, z = zbase + tz;
+    const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y), cz = z < 0 ? 0 : (z > nz - 1 ? nz - 1 : z);
+    auto lane_of = [=](int yy, int zz) {        // thread that holds column (yy, zz); outside the tile: this thread
+        const int ly = yy - ybase, lz = zz - zbase;
+        return (ly >= 0 && ly < TY && lz >= 0 && lz < TZ) ? ly * TZ + lz : t;
+    };
+    const int lN = lane_of(cy + 1 > ny - 1 ? ny - 1 : cy + 1, cz), lS = lane_of(cy - 1 < 0 ? 0 : cy - 1, cz);
+    const int lT = lane_of(cy, cz + 1 > nz - 1 ? nz - 1 : cz + 1), lB = lane_of(cy, cz - 1 < 0 ? 0 : cz - 1);
+    const bool writer = ty >= 1 && ty <= TY - 2 && tz >= 1 && tz <= TZ - 2 && y < ny && z < nz;
+    const int xs = (int)blockIdx.z * ch;
+    const int xe = xs + ch < nx ? xs + ch : nx;
+    const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
+    const int j1 = xe;      // at the end of the domain row xe is the clamped last row (see sweep2d_stream)
+    const long plane = (long)ny * nz, plane6 = (long)NF3 * plane;
+    const unsigned pbytes = (unsigned)(plane6 * 8), fstride = (unsigned)(plane * 8);
+    const unsigned cell = (unsigned)cy * (unsigned)nz + (unsigned)cz;
+    const unsigned vc = cell * 8u;
+    const unsigned vst = writer ? vc : 0xFFFFFFF0u;
+    auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
+    auto load_row = [&](int x, double v[NF3]) {
+        const PlaneRef p(src + (long)x * plane6, pbytes);
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) v[f] = p.ld(vc, (unsigned)f * fstride);
+    };
+    auto load_act = [&](int x) { return PlaneRef(active + (long)x * plane, (unsigned)plane).ldb(cell); };
+
+    double R[RD][NF3];
+    double pq[NS3] = {0, 0, 0, 0, 0}, pcoef[NS3] = {0, 0, 0, 0, 0}, prho = 0.0;
+    double mwp[4] = {0, 0, 0, 0}, mwpD = 0.0;
+    unsigned char act_j;
+
+    auto row = [&](int j, double* Rw, const double* Rc, const double* Re, bool first) {
+        double h[3][NF3];
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) h[0][f] = half_slope(Re[f], Rc[f], Rw[f]);
+        load_row(clampx(j + RD - 1), Rw);
+        const unsigned char act_n = load_act(clampx(j + 1));
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) {
+            h[1][f] = half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS]);
+            h[2][f] = half_slope(lraw[f * NT + lT], Rc[f], lraw[f * NT + lB]);
+        }
+        StreamA3 A;
+        phaseA3s(K, Rc, h, mask_of(act_j != 0), A);
+        if (first) {    // clamp-to-self on the West side
+            mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwp[3] = A.mw[3]; mwpD = A.me[S3_DYE];
+        }
+        stream_west3(A.q, A.coef, mwp, mwpD);
+        {   // finish row j-1 (stores dropped for the row that belongs to the previous chunk)
+            const int x = j - 1;
+            const unsigned vs = x >= xs ? vst : 0xFFFFFFF0u;
+            const double nU = stream_finish3(pq[S3_U], pcoef[S3_U], A.me[S3_U], lmy[0 * NT + lN], lmy[5 * NT + lS],
+                                             lmz[0 * NT + lT], lmz[5 * NT + lB]);
+            const double nV = stream_finish3(pq[S3_V], pcoef[S3_V], A.me[S3_V], lmy[1 * NT + lN], lmy[6 * NT + lS],
+                                             lmz[1 * NT + lT], lmz[6 * NT + lB]);
+            const double nW = stream_finish3(pq[S3_W], pcoef[S3_W], A.me[S3_W], lmy[2 * NT + lN], lmy[7 * NT + lS],
+                                             lmz[2 * NT + lT], lmz[7 * NT + lB]);
+            const double nT = stream_finish3(pq[S3_T], pcoef[S3_T], A.me[S3_T], lmy[3 * NT + lN], lmy[3 * NT + lS],
+                                             lmz[3 * NT + lT], lmz[8 * NT + lB]);
+            const double nD = stream_finish3(pq[S3_DYE], pcoef[S3_DYE], A.me[S3_DYE], lmy[4 * NT + lN], lmy[4 * NT + lS],
+                                             lmz[4 * NT + lT], lmz[4 * NT + lB]);
+            const PlaneRef d(dst + (long)(x < xlo ? xlo : x) * plane6, pbytes);
+            d.st(vs, (unsigned)F3_RHO * fstride, prho);
+            d.st(vs, (unsigned)F3_T * fstride, nT);
+            d.st(vs, (unsigned)F3_U * fstride, nU);
+            d.st(vs, (unsigned)F3_V * fstride, nV);
+            d.st(vs, (unsigned)F3_W * fstride, nW);
+            d.st(vs, (unsigned)F3_DYE * fstride, nD);
+        }
+        __syncthreads();        // every read of row j's stored values and row j-1's messages is done
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = Re[f];
+#pragma unroll
+        for (int e = 0; e < NS3; ++e) { lmy[e * NT + t] = A.ms[e]; lmz[e * NT + t] = A.mb[e]; }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) lmy[(5 + e) * NT + t] = A.mn[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lmz[(5 + e) * NT + t] = A.mt[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NS3; ++e) { pq[e] = A.q[e]; pcoef[e] = A.coef[e]; }
+        prho = A.rho;
+        mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwp[3] = A.mw[3]; mwpD = A.me[S3_DYE];
+        act_j = act_n;
+    };
+
+#pragma unroll
+    for (int u = 0; u < RD; ++u) load_row(clampx(j0 - 1 + u), R[u]);
+    act_j = load_act(j0);
+#pragma unroll
+    for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = R[1][f];
+    // the message tiles are read (and the result dropped) in the first iteration: define them
+    for (int e = 0; e < 8; ++e) lmy[e * NT + t] = 0.0;
+    for (int e = 0; e < 9; ++e) lmz[e * NT + t] = 0.0;
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): see sweep2d_stream
+    int j = j0;
+    while (j <= j1) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            row(j, R[u % RD], R[(u + 1) % RD], R[(u + 2) % RD], j == j0);
+            ++j;
+            if (j > j1) break;
+        }
+    }
+}
+
 // correctPrevTime: prev <- pp + 0.5*(c - pp); Density and Temperature in every cell, the
 // other fields only where the cell is active.  Grid: (ceil(plane/256), nf, nx).
 __global__ void __launch_bounds__(256)
@@ -1059,13 +1182,35 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, KK, src, dst, act,     \
                               p.nx, p.ny, p.nz, xlo, xhi, ch);                                     \
     } while (0)
+#define LAUNCH_STREAM3(TY, TZ, MINW, RDV)                                                           \
+    do {                                                                                           \
+        auto kern = sweep3d_stream<TY, TZ, MINW, RDV>;                                             \
+        const size_t lds = (size_t)(NF3 + 8 + 9) * TY * TZ * sizeof(double);                       \
+        static bool attr_set[64] = {};                                                             \
+        if (lds > 64 * 1024 && !attr_set[h->device & 63]) {                                        \
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                \
+            attr_set[h->device & 63] = true;                                                       \
+        }                                                                                          \
+        dim3 block(TY * TZ), grid((p.nz + TZ - 3) / (TZ - 2), (p.ny + TY - 3) / (TY - 2),          \
+                                  (p.nx + ch - 1) / ch);                                           \
+        hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, h->KF, src, dst, act,  \
+                              p.nx, p.ny, p.nz, xlo, xhi, ch);                                     \
+    } while (0)
         if (fast) {
             switch (h->variant < 0 ? 0 : h->variant) {
+                case 11: LAUNCH_STREAM3(16, 16, 1, 3); break;
+                case 12: LAUNCH_STREAM3(8, 32, 2, 3); break;
+                case 13: LAUNCH_STREAM3(16, 32, 1, 3); break;
+                case 14: LAUNCH_STREAM3(16, 16, 2, 4); break;
+                case 15: LAUNCH_STREAM3(8, 16, 2, 3); break;
+                case 16: LAUNCH_STREAM3(16, 32, 2, 3); break;
                 case 1: LAUNCH_MARCH3(MathFast3, h->KF, 8, 32, 2); break;
                 case 2: LAUNCH_MARCH3(MathFast3, h->KF, 16, 32, 1); break;
                 case 3: LAUNCH_MARCH3(MathFast3, h->KF, 8, 16, 2); break;
                 case 4: LAUNCH_MARCH3(MathFast3, h->KF, 16, 16, 2); break;
-                default: LAUNCH_MARCH3(MathFast3, h->KF, 16, 16, 1); break;
+                case 5: LAUNCH_MARCH3(MathFast3, h->KF, 16, 16, 1); break;
+                default: LAUNCH_STREAM3(16, 16, 2, 3); break;
             }
         } else {
             switch (h->variant < 0 ? 0 : h->variant) {
@@ -1075,6 +1220,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
             }
         }
 #undef LAUNCH_MARCH3
+#undef LAUNCH_STREAM3
     }
     HIP_TRY(hipGetLastError());
     if (h->timing) { ev.kind = fused ? 1 : 0; h->ev_used.push_back(ev); }
@@ -1366,6 +1512,7 @@ const char* cfd_kernel_name(cfd_handle* h) {
         // slower one; it runs only when a launch shape is asked for explicitly
         if ((h->p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant < 0))
             return fast ? "sweep3d_simple<fast>" : "sweep3d_simple<strict>";
+        if (fast && (h->variant < 1 || h->variant > 5)) return "sweep3d_stream<fast>";
         return fast ? "sweep3d_march<fast>" : "sweep3d_march<strict>";
     }
     if (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) return fast ? "sweep2d_simple<fast>" : "sweep2d_simple<strict>";

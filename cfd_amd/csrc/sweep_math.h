@@ -410,6 +410,9 @@ struct FastConsts {
     double cUa, cVb;        // 2 (kxxm + kyy), 2 (kxx + kyym)
     double kxx2, kyy2;      // 2 kxx, 2 kyy
     double kxxd, kyyd, cDg; // dyef kxx, dyef kyy, 2 dyef (kxx + kyy)
+    // streaming form (3-D)
+    double kzz2, kzzd;      // 2 kzz, dyef kzz
+    double cUa3, cVb3, cWc3, cDg3;  // 2 (kxxm + kyy + kzz), 2 (kxx + kyym + kzz), 2 (kxx + kyy + kzzm), 2 dyef (kxx + kyy + kzz)
 };
 
 inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy, double dz = 1.0) {
@@ -424,6 +427,9 @@ inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy, d
     f.cUa = 2.0 * (f.kxxm + f.kyy);  f.cVb = 2.0 * (f.kxx + f.kyym);
     f.kxx2 = 2.0 * f.kxx;  f.kyy2 = 2.0 * f.kyy;
     f.kxxd = c.dyef * f.kxx;  f.kyyd = c.dyef * f.kyy;  f.cDg = 2.0 * (f.kxxd + f.kyyd);
+    f.kzz2 = 2.0 * f.kzz;  f.kzzd = c.dyef * f.kzz;
+    f.cUa3 = 2.0 * (f.kxxm + f.kyy + f.kzz);  f.cVb3 = 2.0 * (f.kxx + f.kyym + f.kzz);
+    f.cWc3 = 2.0 * (f.kxx + f.kyy + f.kzzm);  f.cDg3 = 2.0 * (f.kxxd + f.kyyd + f.kzzd);
     return f;
 }
 
@@ -1066,6 +1072,123 @@ CFD_HD void phaseB3f(const FastConsts& k, const PhaseA3F& C, const ShareX3F& XP,
     out[E3_W] = fma(-gW, select(mask_of(C.phi[E3_W] != 0.0), C.rinv, 1.0), C.phi[E3_W]);
     out[E3_T] = fma(-gT, select(mask_of(C.phi[E3_T] != 0.0), C.rinv * k.rcv, 1.0), C.phi[E3_T]);
     out[E3_DYE] = fma(-gD, select(mask_of(C.phi[E3_DYE] != 0.0), C.rinv, 1.0), C.phi[E3_DYE]);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// General 3-D case, streaming form: the 3-D counterpart of phaseA2s (q, coef and one pre-scaled
+// message per face neighbour).  Equation slots: U, V, W, Temperature, Dye.
+// ------------------------------------------------------------------------------------------
+enum { S3_U = 0, S3_V, S3_W, S3_T, S3_DYE, NS3 };
+
+struct StreamA3 {
+    double rho;         // new Density (complete)
+    double q[NS3];
+    double coef[NS3];
+    double me[NS3];     // message to the West neighbour (this cell is its East)
+    double mw[4];       // message to the East neighbour: U, V, W, T (its Dye entry equals me's)
+    double ms[NS3];     // message to the South neighbour (this cell is its North)
+    double mn[3];       // message to the North neighbour: U, V, W (T and Dye entries equal ms's)
+    double mb[NS3];     // message to the Bottom neighbour (this cell is its Top)
+    double mt[4];       // message to the Top neighbour: U, V, W, T (Dye entry equals mb's)
+};
+
+CFD_HD void phaseA3s(const FastConsts& k, const double c[NF3], const double h[3][NF3], lane_mask act, StreamA3& o) {
+    const double rc[3] = {k.rcx, k.rcy, k.rcz};
+    double div[NE3] = {0, 0, 0, 0, 0, 0};
+    double dmu[3][3];       // dmu[d][q] = mu_f (u_q)_f on the upper face of direction d minus the lower face
+    double pair[3];         // pair[0] = X-neighbours' Y-face term, [1] = X-neighbours' Z-face term, [2] = Z-neighbours' Y-face term
+    for (int d = 0; d < 3; ++d) {
+        double fu[NF3], fl[NF3];
+        for (int q = 0; q < NF3; ++q) { fu[q] = c[q] + h[d][q]; fl[q] = c[q] - h[d][q]; }
+        const double muU = mu_stream(k, fu[F3_T]), muL = mu_stream(k, fl[F3_T]);
+        const double pU = (k.R * fu[F3_T]) * fu[F3_RHO], pL = (k.R * fl[F3_T]) * fl[F3_RHO];
+        const double mU = fu[F3_RHO] * fu[F3_U + d], mL = fl[F3_RHO] * fl[F3_U + d];
+        // flux differences across direction d (products rounded, then subtracted)
+        div[E3_RHO] = fma(rc[d], mU - mL, div[E3_RHO]);
+        for (int cc = 0; cc < 3; ++cc) {
+            double dd = mU * fu[F3_U + cc] - mL * fl[F3_U + cc];
+            if (cc == d) dd = dd + (pU - pL);
+            div[E3_U + cc] = fma(rc[d], dd, div[E3_U + cc]);
+        }
+        div[E3_T] = fma(rc[d], k.cv * (mU * fu[F3_T] - mL * fl[F3_T]) + (pU * fu[F3_U + d] - pL * fl[F3_U + d]), div[E3_T]);
+        div[E3_DYE] = fma(rc[d], mU * fu[F3_DYE] - mL * fl[F3_DYE], div[E3_DYE]);
+        double au[3], al[3];
+        for (int q = 0; q < 3; ++q) { au[q] = muU * fu[F3_U + q]; al[q] = muL * fl[F3_U + q]; dmu[d][q] = au[q] - al[q]; }
+        // paired terms: difference over the faces of d of (mu u_a) u_b - mu u_a - u_b
+        if (d == 1) {
+            pair[0] = ((au[0] * fu[F3_V] - al[0] * fl[F3_V]) - dmu[1][0]) - (fu[F3_V] - fl[F3_V]);     // [Mew,U][V] X Y
+            pair[2] = ((au[2] * fu[F3_V] - al[2] * fl[F3_V]) - dmu[1][2]) - (fu[F3_V] - fl[F3_V]);     // [Mew,W][V] Z Y
+        }
+        if (d == 2)
+            pair[1] = ((au[0] * fu[F3_W] - al[0] * fl[F3_W]) - dmu[2][0]) - (fu[F3_W] - fl[F3_W]);     // [Mew,U][W] X Z
+    }
+    // ---- centre products
+    const double muC = mu_stream(k, c[F3_T]);
+    double a[3], a2[3];
+    for (int q = 0; q < 3; ++q) { a[q] = muC * c[F3_U + q]; a2[q] = a[q] * a[q]; }
+    const double g = muC * c[F3_DYE], kt = k.k * c[F3_T];
+    double pc[3];
+    for (int d = 0; d < 3; ++d) {
+        double v = kt + fma(k.c83h, a2[d], k.c83n * a[d]);
+        for (int q = 0; q < 3; ++q)
+            if (q != d) v = v + fma(0.5, a2[q], -a[q]);
+        pc[d] = v;
+    }
+    // ---- messages: second-difference part s, cross-difference part t; s + t goes to the lower
+    // neighbour (this cell is its upper one), s - t to the upper neighbour
+    {   // X
+        const double sU = k.kxxm * a[0], sV = k.kxx * a[1], sW = k.kxx * a[2], sT = k.kxx * pc[0];
+        const double tU = fma(k.kxy, dmu[1][1], k.kxz * dmu[2][2]), tV = k.kxym * dmu[1][0], tW = k.kxzm * dmu[2][0];
+        const double tT = fma(k.kxy, pair[0], k.kxz * pair[1]);
+        o.me[S3_U] = sU + tU; o.me[S3_V] = sV + tV; o.me[S3_W] = sW + tW; o.me[S3_T] = sT + tT; o.me[S3_DYE] = k.kxxd * g;
+        o.mw[S3_U] = sU - tU; o.mw[S3_V] = sV - tV; o.mw[S3_W] = sW - tW; o.mw[S3_T] = sT - tT;
+    }
+    {   // Y
+        const double sU = k.kyy * a[0], sV = k.kyym * a[1], sW = k.kyy * a[2];
+        const double tU = k.kxym * dmu[0][1], tV = fma(k.kxy, dmu[0][0], k.kyz * dmu[2][2]), tW = k.kyzm * dmu[2][1];
+        o.ms[S3_U] = sU + tU; o.ms[S3_V] = sV + tV; o.ms[S3_W] = sW + tW; o.ms[S3_T] = k.kyy * pc[1]; o.ms[S3_DYE] = k.kyyd * g;
+        o.mn[S3_U] = sU - tU; o.mn[S3_V] = sV - tV; o.mn[S3_W] = sW - tW;
+    }
+    {   // Z
+        const double sU = k.kzz * a[0], sV = k.kzz * a[1], sW = k.kzzm * a[2], sT = k.kzz * pc[2];
+        const double tU = k.kxzm * dmu[0][2], tV = k.kyzm * dmu[1][2], tW = fma(k.kxz, dmu[0][0], k.kyz * dmu[1][1]);
+        const double tT = k.kyz * pair[2];
+        o.mb[S3_U] = sU + tU; o.mb[S3_V] = sV + tV; o.mb[S3_W] = sW + tW; o.mb[S3_T] = sT + tT; o.mb[S3_DYE] = k.kzzd * g;
+        o.mt[S3_U] = sU - tU; o.mt[S3_V] = sV - tV; o.mt[S3_W] = sW - tW; o.mt[S3_T] = sT - tT;
+    }
+    // ---- the cell's own part
+    const double gU = fma(k.cUa3, a[0], div[E3_U]), gV = fma(k.cVb3, a[1], div[E3_V]), gW = fma(k.cWc3, a[2], div[E3_W]);
+    const double gT = fma(k.kxx2, pc[0], fma(k.kyy2, pc[1], fma(k.kzz2, pc[2], div[E3_T])));
+    const double gD = fma(k.cDg3, g, div[E3_DYE]);
+    const double rinv = fast_rcp(c[F3_RHO]);
+    const double keep = select(act, 1.0, 0.0);
+    o.coef[S3_U] = select(act & mask_of(c[F3_U] != 0.0), rinv, keep);
+    o.coef[S3_V] = select(act & mask_of(c[F3_V] != 0.0), rinv, keep);
+    o.coef[S3_W] = select(act & mask_of(c[F3_W] != 0.0), rinv, keep);
+    o.coef[S3_T] = select(mask_of(c[F3_T] != 0.0), rinv * k.rcv, 1.0);
+    o.coef[S3_DYE] = select(act & mask_of(c[F3_DYE] != 0.0), rinv, keep);
+    o.q[S3_U] = fma(-o.coef[S3_U], gU, c[F3_U]);
+    o.q[S3_V] = fma(-o.coef[S3_V], gV, c[F3_V]);
+    o.q[S3_W] = fma(-o.coef[S3_W], gW, c[F3_W]);
+    o.q[S3_T] = fma(-o.coef[S3_T], gT, c[F3_T]);
+    o.q[S3_DYE] = fma(-o.coef[S3_DYE], gD, c[F3_DYE]);
+    o.rho = c[F3_RHO] - div[E3_RHO];
+}
+
+// q += coef * (message from the West neighbour); mwD: that message's Dye entry
+CFD_HD void stream_west3(double q[NS3], const double coef[NS3], const double mw[4], double mwD) {
+    q[S3_U] = fma(coef[S3_U], mw[S3_U], q[S3_U]);
+    q[S3_V] = fma(coef[S3_V], mw[S3_V], q[S3_V]);
+    q[S3_W] = fma(coef[S3_W], mw[S3_W], q[S3_W]);
+    q[S3_T] = fma(coef[S3_T], mw[S3_T], q[S3_T]);
+    q[S3_DYE] = fma(coef[S3_DYE], mwD, q[S3_DYE]);
+}
+
+// new value of one field: q (West folded in) plus the East, North, South, Top and Bottom messages
+CFD_HD double stream_finish3(double q, double coef, double from_e, double from_n, double from_s, double from_t,
+                             double from_b) {
+    return fma(coef, (((from_e + from_n) + from_s) + from_t) + from_b, q);
 }
 
 }  // namespace cfd

@@ -214,3 +214,48 @@ extern "C" void hm_sweep2d_stream(int nx, int ny, double dx, double dy, double d
             out[F2_DYE][id(x, y)] = stream_finish(q[S2_DYE], C.coef[S2_DYE], E.me[S2_DYE], N.ms[S2_DYE], S.ms[S2_DYE]);
         }
 }
+
+extern "C" void hm_sweep3d_stream(int nx, int ny, int nz, double dx, double dy, double dz, double dt, double lambda,
+                                  double suth, double R, double cv, double k, double dyef,
+                                  const double* const in[6], const uint8_t* active, double* const out[6]) {
+    SweepConsts K = make_consts(dx, dy, dz, dt, lambda, suth, R, cv, k, dyef);
+    FastConsts F = make_fast_consts(K, dx, dy, dz);
+    std::vector<StreamA3> pa((size_t)nx * ny * nz);
+    auto id = [&](int x, int y, int z) { return ((size_t)x * ny + y) * nz + z; };
+    auto cl = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y)
+            for (int z = 0; z < nz; ++z) {
+                double c[6], nb[6][6], h[3][6];
+                const size_t n6[6] = {id(cl(x + 1, nx - 1), y, z), id(cl(x - 1, nx - 1), y, z),
+                                      id(x, cl(y + 1, ny - 1), z), id(x, cl(y - 1, ny - 1), z),
+                                      id(x, y, cl(z + 1, nz - 1)), id(x, y, cl(z - 1, nz - 1))};
+                for (int q = 0; q < 6; ++q) {
+                    c[q] = in[q][id(x, y, z)];
+                    for (int s = 0; s < 6; ++s) nb[s][q] = in[q][n6[s]];
+                }
+                half_slopes3(c, nb, h);
+                phaseA3s(F, c, h, active[id(x, y, z)] != 0, pa[id(x, y, z)]);
+            }
+    const int fld[5] = {F3_U, F3_V, F3_W, F3_T, F3_DYE};
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y)
+            for (int z = 0; z < nz; ++z) {
+                const size_t i = id(x, y, z);
+                const StreamA3& C = pa[i];
+                const StreamA3& E = pa[id(cl(x + 1, nx - 1), y, z)];
+                const StreamA3& W = pa[id(cl(x - 1, nx - 1), y, z)];
+                const StreamA3& N = pa[id(x, cl(y + 1, ny - 1), z)];
+                const StreamA3& S = pa[id(x, cl(y - 1, ny - 1), z)];
+                const StreamA3& T = pa[id(x, y, cl(z + 1, nz - 1))];
+                const StreamA3& B = pa[id(x, y, cl(z - 1, nz - 1))];
+                double q[5] = {C.q[0], C.q[1], C.q[2], C.q[3], C.q[4]};
+                stream_west3(q, C.coef, W.mw, W.me[S3_DYE]);
+                out[F3_RHO][i] = C.rho;
+                for (int e = 0; e < 5; ++e) {
+                    const double fs = e < 3 ? S.mn[e] : S.ms[e];
+                    const double fb = e < 4 ? B.mt[e] : B.mb[e];
+                    out[fld[e]][i] = stream_finish3(q[e], C.coef[e], E.me[e], N.ms[e], fs, T.mb[e], fb);
+                }
+            }
+}

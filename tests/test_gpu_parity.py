@@ -334,12 +334,16 @@ def test_fast_arithmetic_drift_over_steps():
     print("fast-vs-strict drift after 90 sweeps:", worst)
 
 
-@pytest.mark.parametrize("kernel_flag", [0, 1])
+@pytest.mark.parametrize("kernel_flag,variant,chunk", [(0, -1, 32), (1, -1, 32), (0, 4, 3), (0, 5, 32), (0, 10, 1),
+                                                        (0, 12, 5), (0, 15, 32), (0, 14, 2)])
 @pytest.mark.parametrize("case", ["small", "small_zero_v", "thin", "synthetic"])
-def test_fast_arithmetic_3d_within_1e13_per_sweep(case, kernel_flag):
-    """The 3-D form of the re-associated arithmetic, per-cell and tiled kernel: every sweep, started
-    from the oracle's own state, within 1e-13 of the field scale of Oracle B."""
+def test_fast_arithmetic_3d_within_1e13_per_sweep(case, kernel_flag, variant, chunk, monkeypatch):
+    """The 3-D forms of the re-associated arithmetic -- per-cell kernel, tiled kernel with shared
+    products, tiled kernel with streamed messages, in several launch shapes and chunk lengths: every
+    sweep, started from the oracle's own state, within 1e-13 of the field scale of Oracle B."""
     from cfd_amd import cases
+    monkeypatch.setenv("CFD_VARIANT", str(variant))
+    monkeypatch.setenv("CFD_CHUNK", str(chunk))
     params, fields, active = {
         "small": lambda: small_case(9, 20, 13, 6),
         "small_zero_v": lambda: small_case(7, 6, 5, 2, True),
@@ -351,7 +355,7 @@ def test_fast_arithmetic_3d_within_1e13_per_sweep(case, kernel_flag):
     for sweep in range(3):
         cur = b.read_fields(0)
         g = _gpu_graph(params, cur, active, FAST | kernel_flag)
-        assert g.kernel_name() == ("sweep3d_simple<fast>" if kernel_flag else "sweep3d_march<fast>")
+        assert g.kernel_name().startswith("sweep3d_simple<fast>" if kernel_flag else "sweep3d_")
         g.sweep(True)
         b.sweep(sweep == 0)
         errs = field_errors(g.read_fields(0), b.read_fields(0))
@@ -366,7 +370,7 @@ def test_tiled_3d_matches_per_cell_3d_bitwise(flags, monkeypatch):
     """Both 3-D kernels evaluate the same expressions: 70 x 45 x 61 (several tiles and chunks, ragged
     edges), two steps, every slot bit-identical."""
     from cfd_amd import cases
-    monkeypatch.setenv("CFD_VARIANT", "0")      # the tiled kernel also for strict arithmetic
+    monkeypatch.setenv("CFD_VARIANT", "5")      # the product-sharing tiled kernel, for both arithmetics
     params, fields, active = cases.synthetic_3d(70, 45, 61)
     ga = _gpu_graph(params, fields, active, flags)
     gb = _gpu_graph(params, fields, active, flags | 1)
@@ -412,6 +416,31 @@ def test_streaming_kernel_within_1e13_per_sweep(case, variant, chunk, monkeypatc
         fa, fb = ga.read_fields(rel), gb.read_fields(rel)
         for k in range(7):
             assert bits_equal(fa[k], fb[k]), (rel, PROPS[k])
+
+
+def test_streaming_3d_kernel_shapes_agree_bitwise(monkeypatch):
+    """The streaming 3-D kernel gives the same bits for every tile shape, ring depth and chunk length
+    (70 x 45 x 61, two steps, inactive block inside), and stays within 1e-12 of the strict kernel."""
+    from cfd_amd import cases
+    params, fields, active = cases.synthetic_3d(70, 45, 61)
+    params = dict(params, dt=1e-7)
+    outs = []
+    for variant, chunk in [(10, 32), (12, 7), (14, 1), (15, 70), (13, 4)]:
+        monkeypatch.setenv("CFD_VARIANT", str(variant))
+        monkeypatch.setenv("CFD_CHUNK", str(chunk))
+        g = _gpu_graph(params, fields, active, FAST)
+        assert g.kernel_name() == "sweep3d_stream<fast>"
+        g.step(2)
+        outs.append([g.read_fields(rel) for rel in range(3)])
+    for o in outs[1:]:
+        for rel in range(3):
+            for k in range(7):
+                assert bits_equal(o[rel][k], outs[0][rel][k]), (rel, PROPS[k])
+    monkeypatch.setenv("CFD_VARIANT", "-1")
+    gs = _gpu_graph(params, fields, active, 0)
+    gs.step(2)
+    for rel in range(3):
+        assert max(field_errors(outs[0][rel], gs.read_fields(rel))) <= 1e-12
 
 
 def test_fast_tiled_matches_fast_per_cell_bitwise():

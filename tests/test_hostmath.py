@@ -100,7 +100,8 @@ def test_sweep2d_fast_math_close(hm, shape, seed, zero_v, entry):
 
 @pytest.mark.parametrize("shape,seed,zero_v", [((7, 6, 5), 1, False), ((3, 3, 3), 2, True), ((12, 9, 1), 3, False),
                                                 ((4, 1, 6), 4, False), ((1, 1, 1), 5, False), ((9, 8, 2), 6, True)])
-def test_sweep3d_fast_math_close(hm, shape, seed, zero_v):
+@pytest.mark.parametrize("entry", ["hm_sweep3d_fast", "hm_sweep3d_stream"])
+def test_sweep3d_fast_math_close(hm, shape, seed, zero_v, entry):
     nx, ny, nz = shape
     params, fields, active = small_case(nx, ny, nz, seed, zero_v)
     p = oracle_params(params)
@@ -111,7 +112,7 @@ def test_sweep3d_fast_math_close(hm, shape, seed, zero_v):
         cur = [b.read_fields(0)[i].copy() for i in live]
         b.sweep(sweep == 0)
         out = [np.empty(nx * ny * nz) for _ in range(6)]
-        hm.hm_sweep3d_fast(nx, ny, nz, d(p["dx"]), d(p["dy"]), d(p["dz"]), d(p["dt"]), d(p["lambda_"]),
+        getattr(hm, entry)(nx, ny, nz, d(p["dx"]), d(p["dy"]), d(p["dz"]), d(p["dt"]), d(p["lambda_"]),
                            d(p["suth"]), d(p["R"]), d(p["cv"]), d(p["k"]), d(p["dye_f"]), _ptrs(cur),
                            active.ctypes.data_as(ctypes.c_void_p), _ptrs(out))
         fb = b.read_fields(0)
