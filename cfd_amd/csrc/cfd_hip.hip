@@ -1107,15 +1107,16 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         hipExtLaunchKernelGGL((sweep2d_march<M, NT, MINW, PF>), grid, block, 0, h->stream, ea, eb, \
                               0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch);                     \
     } while (0)
-#define LAUNCH_STREAM(NT, MINW, WC)                                                                 \
+#define LAUNCH_STREAM(NT, MINW, WC) LAUNCH_STREAM_RD(NT, MINW, WC, 3)
+#define LAUNCH_STREAM_RD(NT, MINW, WC, RDV)                                                         \
     do {                                                                                           \
         dim3 block(NT), grid((p.ny + WC - 1) / WC, (p.nx + ch - 1) / ch);                          \
         if (fpp)                                                                                   \
-            hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, true, 3, WC>), grid, block, 0,         \
+            hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, true, RDV, WC>), grid, block, 0,       \
                                   h->stream, ea, eb, 0, h->KF, src, dst, act, p.nx, p.ny, xlo,     \
                                   xhi, ch, fpp, fprev);                                            \
         else                                                                                       \
-            hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, false, 3, WC>), grid, block, 0,        \
+            hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, false, RDV, WC>), grid, block, 0,      \
                                   h->stream, ea, eb, 0, h->KF, src, dst, act, p.nx, p.ny, xlo,     \
                                   xhi, ch, fpp, fprev);                                            \
         fused = fpp != nullptr;                                                                    \
@@ -1127,6 +1128,11 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                 case 22: LAUNCH_STREAM(64, 3, 62); break;
                 case 23: LAUNCH_STREAM(256, 3, 254); break;
                 case 24: LAUNCH_STREAM(256, 3, 240); break;     // tiles aligned to 128-byte lines
+                case 25: LAUNCH_STREAM_RD(128, 2, 126, 4); break;
+                case 26: LAUNCH_STREAM_RD(128, 2, 126, 5); break;
+                case 27: LAUNCH_STREAM_RD(256, 2, 240, 4); break;
+                case 28: LAUNCH_STREAM_RD(256, 2, 240, 5); break;
+                case 29: LAUNCH_STREAM_RD(128, 2, 112, 5); break;
                 case 1: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, true); break;
                 case 2: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, false); break;
                 case 3: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, true); break;
@@ -1157,6 +1163,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
 #undef LAUNCH_MARCH
 #undef LAUNCH_MARCH2
 #undef LAUNCH_STREAM
+#undef LAUNCH_STREAM_RD
     } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant < 0)) {
         dim3 block(64), grid((unsigned)((h->plane + 63) / 64), p.nx);
         if (fast)
@@ -1517,7 +1524,7 @@ const char* cfd_kernel_name(cfd_handle* h) {
     }
     if (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) return fast ? "sweep2d_simple<fast>" : "sweep2d_simple<strict>";
     const int v = h->variant < 0 ? 8 : h->variant;
-    if (fast && v >= 20 && v <= 24) return "sweep2d_stream<fast>";
+    if (fast && v >= 20 && v <= 29) return "sweep2d_stream<fast>";
     if (v >= 8) return fast ? "sweep2d_march2<fast>" : "sweep2d_march2<strict>";
     return fast ? "sweep2d_march<fast>" : "sweep2d_march<strict>";
 }

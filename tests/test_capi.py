@@ -61,3 +61,19 @@ def test_create_fails_loudly_without_gpu():
     with pytest.raises(_capi.CfdError) as e:
         AdjGraph(params, fields, active)
     assert e.value.code == _capi.CFD_E_DEVICE
+
+
+def test_compiled_host_fails_loudly_without_gpu():
+    """The C++ host links against the C ABI alone; with no usable GPU it must exit non-zero with the
+    library's error text, not fall back to anything."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "driver", "cfd_main")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "driver")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=100)
+    assert out.returncode != 0
+    assert "cfd_create" in out.stderr

@@ -457,6 +457,29 @@ def test_fast_tiled_matches_fast_per_cell_bitwise():
             assert bits_equal(fa[k], fb[k]), (rel, PROPS[k])
 
 
+def test_compiled_host_prints_reference_stdout():
+    """driver/cfd_main (C++ over the C ABI, no Python in the loop) runs the shipped case for five
+    steps and prints the same blocks as the golden transcript (generated by the literal oracle)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "driver", "cfd_main")
+    assert os.path.exists(exe), "build it with make -C driver (done by __graft_entry__.build())"
+    out = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stderr
+    got = out.stdout.splitlines()
+    assert got[0] == "starting ..... "
+    want = open(os.path.join(root, "tests", "golden", "shipped_case_stdout_5steps.txt")).read().splitlines()
+    assert len(got) - 1 == len(want)
+    for a, b in zip(got[1:], want):
+        if a.startswith("totalDensity: "):
+            # the density sum is a tree on the device and a left fold in the reference
+            x, y = float(a.split()[1]), float(b.split()[1])
+            assert abs(x - y) <= 1e-12 * abs(y), (a, b)
+        else:
+            assert a == b
+
+
 def test_error_paths():
     from cfd_amd import _capi
     from cfd_amd.solver import AdjGraph
