@@ -173,7 +173,10 @@ def main():
     del fields
     updates = cells_per_gpu * world * SWEEPS_PER_STEP * a.steps
     bytes_per_update = BYTES_PER_UPDATE_2D if two_d else BYTES_PER_UPDATE_3D
-    avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+    # plain (unfused) sweeps in the timed region: two per step.  At N > 1 each of them is two or three
+    # launches (interior planes, then the planes next to a ghost plane); their times are summed.
+    plain_sweeps = 2 * a.steps
+    avg_kernel_s = kernel_ms / 1e3 / plain_sweeps
     achieved = cells_per_gpu * bytes_per_update / avg_kernel_s / 1e9
     workload = ("synthetic_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if two_d else \
         ("synthetic_3d %dx%dx%d per GPU" % (a.nx, a.ny, a.nz))
@@ -197,8 +200,8 @@ def main():
                    "fields_finite_at_end": bool(final_density == final_density and abs(final_density) != float("inf"))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(workload),
-                     "kernel": "sweep", "bytes_per_cell_update": bytes_per_update,
-                     "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches,
+                     "kernel": kernel_name, "bytes_per_cell_update": bytes_per_update,
+                     "avg_launch_ms": avg_kernel_s * 1e3, "sweeps": plain_sweeps, "launches": launches,
                      "fused_sweep_filter": {"avg_launch_ms": fused_ms / max(fused_launches, 1),
                                             "launches": fused_launches, "bytes_per_cell": bytes_per_update + 80}},
     }

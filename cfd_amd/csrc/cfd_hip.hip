@@ -72,6 +72,15 @@ struct cfd_handle {
     int chunk;              // x-planes per block of the tiled sweep
     int variant;            // tiled-kernel launch shape (tuning knob)
     bool march3_ok;         // a 3-D x-plane fits 32-bit byte offsets (tiled 3-D kernel usable)
+    // a sweep split into cfd_sweep_begin / cfd_sweep_end
+    struct {
+        bool open, step_time, with_filter, fused;
+        const double* src;
+        double* dst;
+        const double* fpp;
+        double* fprev;
+        int x0, x1;         // the range launched by cfd_sweep_begin
+    } pend;
     // sweep timing
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
@@ -194,9 +203,9 @@ __device__ __forceinline__ void phaseA2_at(const typename M::Consts& K, const do
 template <class M>
 __global__ void __launch_bounds__(64)
 sweep2d_simple(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
-               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi) {
+               const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi) {
     const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    const int x = blockIdx.y;
+    const int x = x0 + (int)blockIdx.y;
     if (y >= ny || x >= nx) return;
     const long plane5 = (long)NF2 * ny;
     const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
@@ -280,10 +289,10 @@ __device__ __forceinline__ void phaseA3_at(const typename M::Consts& K, const do
 template <class M>
 __global__ void __launch_bounds__(64)
 sweep3d_simple(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
-               const uint8_t* __restrict__ active, int nx, int ny, int nz, int xlo, int xhi) {
+               const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi) {
     const long plane = (long)ny * nz;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int x = blockIdx.y;
+    const int x = x0 + (int)blockIdx.y;
     if (i >= plane || x >= nx) return;
     const int y = (int)(i / nz), z = (int)(i - (long)y * nz);
     const int xe = x + 1 > xhi ? xhi : x + 1, xw = x - 1 < xlo ? xlo : x - 1;
@@ -350,14 +359,14 @@ struct PlaneRef {
 template <class M, int NT, int MINW, bool PREFETCH>
 __global__ void __launch_bounds__(NT, MINW)
 sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
-              const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch) {
+              const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int ch) {
     __shared__ double lds[2][M::NSY][NT];
     const int t = threadIdx.x;
     const int y = (int)blockIdx.x * (NT - 2) - 1 + t;
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
     const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
     const bool writer = t >= 1 && t <= NT - 2 && y < ny;
-    const int xs = (int)blockIdx.y * ch;
+    const int xs = x0 + (int)blockIdx.y * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;      // first and last row whose phase A is needed
     const int j1 = xe < xhi ? xe : xhi;
@@ -457,7 +466,7 @@ sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __re
 template <class M, int NT, int MINW, bool FILTER>
 __global__ void __launch_bounds__(NT, MINW)
 sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
-               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch,
+               const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int ch,
                const double* __restrict__ fpp, double* __restrict__ fprev) {
     __shared__ double lds[2][M::NSY][NT];
     __shared__ double lraw[2][NF2][NT];
@@ -470,7 +479,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     const int ln = yn - ybase, ls = ys - ybase;
     const int lnc = ln <= NT - 1 ? ln : t, lsc = ls >= 0 ? ls : t;   // outside the block: own value
     const bool writer = t >= 1 && t <= NT - 2 && y < ny;
-    const int xs = (int)blockIdx.y * ch;
+    const int xs = x0 + (int)blockIdx.y * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
     const int j1 = xe < xhi ? xe : xhi;
@@ -597,7 +606,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
 template <int NT, int MINW, bool FILTER, int RD = 3, int WCOLS = NT - 2>
 __global__ void __launch_bounds__(NT, MINW)
 sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict__ dst,
-               const uint8_t* __restrict__ active, int nx, int ny, int xlo, int xhi, int ch,
+               const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int ch,
                const double* __restrict__ fpp, double* __restrict__ fprev) {
     __shared__ double lmsg[2][6][NT];
     __shared__ double lraw[2][NF2][NT];
@@ -609,7 +618,7 @@ sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     const int ln = yn - ybase, ls = ys - ybase;             // lanes holding columns yn / ys
     const int lnc = ln <= NT - 1 ? ln : t, lsc = ls >= 0 ? ls : t;   // outside the block: own value
     const bool writer = t >= 1 && t <= WCOLS && y < ny;
-    const int xs = (int)blockIdx.y * ch;
+    const int xs = x0 + (int)blockIdx.y * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
     // Rows j0 .. xe get a phase A; row xe is the East neighbour of the chunk's last row.  At the end
@@ -758,7 +767,7 @@ __device__ __forceinline__ void lds_get(const double* __restrict__ l, int st, S&
 template <class M, int TY, int TZ, int MINW>
 __global__ void __launch_bounds__(TY * TZ, MINW)
 sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
-              const uint8_t* __restrict__ active, int nx, int ny, int nz, int xlo, int xhi, int ch) {
+              const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi, int ch) {
     constexpr int NT = TY * TZ;
     constexpr int NSY = sizeof(typename M::SY) / sizeof(double);
     extern __shared__ double smem[];
@@ -777,7 +786,7 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     const int lN = lane_of(cy + 1 > ny - 1 ? ny - 1 : cy + 1, cz), lS = lane_of(cy - 1 < 0 ? 0 : cy - 1, cz);
     const int lT = lane_of(cy, cz + 1 > nz - 1 ? nz - 1 : cz + 1), lB = lane_of(cy, cz - 1 < 0 ? 0 : cz - 1);
     const bool writer = ty >= 1 && ty <= TY - 2 && tz >= 1 && tz <= TZ - 2 && y < ny && z < nz;
-    const int xs = (int)blockIdx.z * ch;
+    const int xs = x0 + (int)blockIdx.z * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
     const int j1 = xe < xhi ? xe : xhi;
@@ -876,7 +885,7 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
 template <int TY, int TZ, int MINW, int RD = 3>
 __global__ void __launch_bounds__(TY * TZ, MINW)
 sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict__ dst,
-               const uint8_t* __restrict__ active, int nx, int ny, int nz, int xlo, int xhi, int ch) {
+               const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi, int ch) {
     constexpr int NT = TY * TZ;
     extern __shared__ double smem[];
     double* const lraw = smem;                  // [NF3][NT]
@@ -893,7 +902,7 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     const int lN = lane_of(cy + 1 > ny - 1 ? ny - 1 : cy + 1, cz), lS = lane_of(cy - 1 < 0 ? 0 : cy - 1, cz);
     const int lT = lane_of(cy, cz + 1 > nz - 1 ? nz - 1 : cz + 1), lB = lane_of(cy, cz - 1 < 0 ? 0 : cz - 1);
     const bool writer = ty >= 1 && ty <= TY - 2 && tz >= 1 && tz <= TZ - 2 && y < ny && z < nz;
-    const int xs = (int)blockIdx.z * ch;
+    const int xs = x0 + (int)blockIdx.z * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
     const int j1 = xe;      // at the end of the domain row xe is the clamped last row (see sweep2d_stream)
@@ -1056,10 +1065,13 @@ static size_t march3_lds_bytes(int nt) {
            sizeof(double);
 }
 
+// x0, x1: the range of owned x-planes to compute (x1 < 0: all of them).
 static int launch_sweep(cfd_handle* h, const double* src, double* dst, const double* fpp = nullptr,
-                        double* fprev = nullptr, bool* did_fuse = nullptr) {
+                        double* fprev = nullptr, bool* did_fuse = nullptr, int x0 = 0, int x1 = -1) {
     bool fused = false;
     const cfd_params& p = h->p;
+    if (x1 < 0) x1 = p.nx;
+    if (x1 <= x0) return CFD_OK;        // empty range: nothing launched, *did_fuse untouched
     const int xlo = p.ghost_lo ? -1 : 0;
     const int xhi = p.ghost_hi ? p.nx : p.nx - 1;
     EventPair ev{};
@@ -1079,45 +1091,45 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
     const bool fast = (p.flags & CFD_FLAG_FAST_MATH) != 0;
     const uint8_t* act = h->d_active + h->plane;
     if (h->two_d && (p.flags & CFD_FLAG_SIMPLE_KERNEL)) {
-        dim3 block(64), grid((p.ny + 63) / 64, p.nx);
+        dim3 block(64), grid((p.ny + 63) / 64, x1 - x0);
         if (fast)
             hipExtLaunchKernelGGL(sweep2d_simple<MathFast2>, grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
-                                  act, p.nx, p.ny, xlo, xhi);
+                                  act, x0, x1, p.ny, xlo, xhi);
         else
             hipExtLaunchKernelGGL(sweep2d_simple<MathStrict2>, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst,
-                                  act, p.nx, p.ny, xlo, xhi);
+                                  act, x0, x1, p.ny, xlo, xhi);
     } else if (h->two_d) {
         const int ch = h->chunk;
 #define LAUNCH_MARCH2(M, KK, NT, MINW)                                                              \
     do {                                                                                           \
-        dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (p.nx + ch - 1) / ch);                    \
+        dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (x1 - x0 + ch - 1) / ch);                    \
         if (fpp)                                                                                   \
             hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW, true>), grid, block, 0, h->stream,  \
-                                  ea, eb, 0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch, fpp,     \
+                                  ea, eb, 0, KK, src, dst, act, x0, x1, p.ny, xlo, xhi, ch, fpp,     \
                                   fprev);                                                          \
         else                                                                                       \
             hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW, false>), grid, block, 0, h->stream, \
-                                  ea, eb, 0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch, fpp,     \
+                                  ea, eb, 0, KK, src, dst, act, x0, x1, p.ny, xlo, xhi, ch, fpp,     \
                                   fprev);                                                          \
         fused = fpp != nullptr;                                                                    \
     } while (0)
 #define LAUNCH_MARCH(M, KK, NT, MINW, PF)                                                          \
     do {                                                                                           \
-        dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (p.nx + ch - 1) / ch);                    \
+        dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (x1 - x0 + ch - 1) / ch);                    \
         hipExtLaunchKernelGGL((sweep2d_march<M, NT, MINW, PF>), grid, block, 0, h->stream, ea, eb, \
-                              0, KK, src, dst, act, p.nx, p.ny, xlo, xhi, ch);                     \
+                              0, KK, src, dst, act, x0, x1, p.ny, xlo, xhi, ch);                     \
     } while (0)
 #define LAUNCH_STREAM(NT, MINW, WC) LAUNCH_STREAM_RD(NT, MINW, WC, 3)
 #define LAUNCH_STREAM_RD(NT, MINW, WC, RDV)                                                         \
     do {                                                                                           \
-        dim3 block(NT), grid((p.ny + WC - 1) / WC, (p.nx + ch - 1) / ch);                          \
+        dim3 block(NT), grid((p.ny + WC - 1) / WC, (x1 - x0 + ch - 1) / ch);                          \
         if (fpp)                                                                                   \
             hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, true, RDV, WC>), grid, block, 0,       \
-                                  h->stream, ea, eb, 0, h->KF, src, dst, act, p.nx, p.ny, xlo,     \
+                                  h->stream, ea, eb, 0, h->KF, src, dst, act, x0, x1, p.ny, xlo,     \
                                   xhi, ch, fpp, fprev);                                            \
         else                                                                                       \
             hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, false, RDV, WC>), grid, block, 0,      \
-                                  h->stream, ea, eb, 0, h->KF, src, dst, act, p.nx, p.ny, xlo,     \
+                                  h->stream, ea, eb, 0, h->KF, src, dst, act, x0, x1, p.ny, xlo,     \
                                   xhi, ch, fpp, fprev);                                            \
         fused = fpp != nullptr;                                                                    \
     } while (0)
@@ -1165,13 +1177,13 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
 #undef LAUNCH_STREAM
 #undef LAUNCH_STREAM_RD
     } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant < 0)) {
-        dim3 block(64), grid((unsigned)((h->plane + 63) / 64), p.nx);
+        dim3 block(64), grid((unsigned)((h->plane + 63) / 64), x1 - x0);
         if (fast)
             hipExtLaunchKernelGGL(sweep3d_simple<MathFast3>, grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
-                                  act, p.nx, p.ny, p.nz, xlo, xhi);
+                                  act, x0, x1, p.ny, p.nz, xlo, xhi);
         else
             hipExtLaunchKernelGGL(sweep3d_simple<MathStrict3>, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst,
-                                  act, p.nx, p.ny, p.nz, xlo, xhi);
+                                  act, x0, x1, p.ny, p.nz, xlo, xhi);
     } else {
         const int ch = h->chunk;
 #define LAUNCH_MARCH3(M, KK, TY, TZ, MINW)                                                          \
@@ -1185,9 +1197,9 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
             attr_set[h->device & 63] = true;                                                       \
         }                                                                                          \
         dim3 block(TY * TZ), grid((p.nz + TZ - 3) / (TZ - 2), (p.ny + TY - 3) / (TY - 2),          \
-                                  (p.nx + ch - 1) / ch);                                           \
+                                  (x1 - x0 + ch - 1) / ch);                                           \
         hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, KK, src, dst, act,     \
-                              p.nx, p.ny, p.nz, xlo, xhi, ch);                                     \
+                              x0, x1, p.ny, p.nz, xlo, xhi, ch);                                     \
     } while (0)
 #define LAUNCH_STREAM3(TY, TZ, MINW, RDV)                                                           \
     do {                                                                                           \
@@ -1200,9 +1212,9 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
             attr_set[h->device & 63] = true;                                                       \
         }                                                                                          \
         dim3 block(TY * TZ), grid((p.nz + TZ - 3) / (TZ - 2), (p.ny + TY - 3) / (TY - 2),          \
-                                  (p.nx + ch - 1) / ch);                                           \
+                                  (x1 - x0 + ch - 1) / ch);                                           \
         hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, h->KF, src, dst, act,  \
-                              p.nx, p.ny, p.nz, xlo, xhi, ch);                                     \
+                              x0, x1, p.ny, p.nz, xlo, xhi, ch);                                     \
     } while (0)
         if (fast) {
             switch (h->variant < 0 ? 0 : h->variant) {
@@ -1364,6 +1376,7 @@ static int sweep_in_place(cfd_handle* h, bool with_filter, bool* did_fuse);
 
 int cfd_sweep(cfd_handle* h, int step_time) {
     if (!h) return fail(CFD_E_ARG, "cfd_sweep: null handle");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_sweep: a split sweep is open (call cfd_sweep_end first)");
     HIP_TRY(hipSetDevice(h->device));
     const double* src = slot_base(h, h->cmt);
     if (step_time) {
@@ -1380,6 +1393,7 @@ int cfd_sweep(cfd_handle* h, int step_time) {
 
 int cfd_time_filter(cfd_handle* h) {
     if (!h) return fail(CFD_E_ARG, "cfd_time_filter: null handle");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_time_filter: a split sweep is open (call cfd_sweep_end first)");
     if (!(h->cat > 1)) return CFD_OK;
     HIP_TRY(hipSetDevice(h->device));
     const int tb = (h->cmt + 2) % 3, tc = (tb + 2) % 3;
@@ -1412,11 +1426,62 @@ static int sweep_in_place(cfd_handle* h, bool with_filter, bool* did_fuse) {
 
 int cfd_sweep_and_filter(cfd_handle* h) {
     if (!h) return fail(CFD_E_ARG, "cfd_sweep_and_filter: null handle");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_and_filter: a split sweep is open (call cfd_sweep_end first)");
     HIP_TRY(hipSetDevice(h->device));
     bool fused = false;
     int rc = sweep_in_place(h, true, &fused);
     if (rc) return rc;
     return fused ? CFD_OK : cfd_time_filter(h);
+}
+
+int cfd_sweep_begin(cfd_handle* h, int step_time, int with_filter) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sweep_begin: null handle");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_begin: a split sweep is already open");
+    if (step_time && with_filter) return fail(CFD_E_ARG, "cfd_sweep_begin: the filter follows a sweep that does not advance time");
+    HIP_TRY(hipSetDevice(h->device));
+    auto& q = h->pend;
+    q.step_time = step_time != 0;
+    q.with_filter = with_filter != 0;
+    q.fused = false;
+    q.src = slot_base(h, h->cmt);
+    q.dst = slot_base(h, step_time ? (h->cmt + 1) % 3 : 3);
+    q.fpp = nullptr;
+    q.fprev = nullptr;
+    if (with_filter && h->cat > 1) {
+        const int tb = (h->cmt + 2) % 3, tc = (tb + 2) % 3;
+        q.fpp = slot_base(h, tc);
+        q.fprev = slot_base(h, tb);
+    }
+    // planes 1 .. nx-2 read owned planes only; plane 0 / nx-1 also read a ghost plane if there is one
+    q.x0 = h->p.ghost_lo ? 1 : 0;
+    q.x1 = h->p.ghost_hi ? h->p.nx - 1 : h->p.nx;
+    if (q.x1 < q.x0) q.x1 = q.x0;
+    int rc = launch_sweep(h, q.src, q.dst, q.fpp, q.fprev, &q.fused, q.x0, q.x1);
+    if (rc) return rc;
+    q.open = true;
+    return CFD_OK;
+}
+
+int cfd_sweep_end(cfd_handle* h) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sweep_end: null handle");
+    if (!h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_end: no split sweep is open");
+    HIP_TRY(hipSetDevice(h->device));
+    auto& q = h->pend;
+    int rc = launch_sweep(h, q.src, q.dst, q.fpp, q.fprev, &q.fused, 0, q.x0);
+    if (rc) return rc;
+    rc = launch_sweep(h, q.src, q.dst, q.fpp, q.fprev, &q.fused, q.x1, h->p.nx);
+    if (rc) return rc;
+    q.open = false;
+    if (q.step_time) {
+        h->cmt = (h->cmt + 1) % 3;
+        h->cat += 1;
+    } else {
+        const int t = h->map[h->cmt];
+        h->map[h->cmt] = h->map[3];
+        h->map[3] = t;
+    }
+    if (q.with_filter && !(q.fpp && q.fused)) return cfd_time_filter(h);
+    return CFD_OK;
 }
 
 int cfd_step(cfd_handle* h, int nsteps) {

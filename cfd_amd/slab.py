@@ -5,8 +5,10 @@ of x-planes and the halo it owes each neighbour is its first / last owned plane.
 layout keeps all live fields of a plane contiguous, so that halo is ONE message per neighbour
 per sweep, sent straight from / received straight into the time slot (no pack kernel).
 
-Per sweep:  exchange ghost planes of the current slot  ->  sweep.
-Per step:   3 x (exchange, sweep); the live filter pass needs no halo and is fused into the third sweep.
+Per sweep:  start the exchange of the current slot's ghost planes, launch every plane that needs no
+            ghost plane, wait for the exchange, launch the first / last plane (interior compute
+            overlaps the transfer).
+Per step:   3 such sweeps; the live filter pass needs no halo and is fused into the third sweep.
 Reduction:  local tree sum of Density, then one all-reduce of a single double.
 
 Domain ends keep the reference's clamp-to-self rule (no wrap-around): rank 0 has no low
@@ -73,9 +75,12 @@ class DistComm:
         import torch.distributed as dist
         self.dist, self.rank, self.world = dist, rank, world
 
-    def exchange(self, backend):
+    def exchange_start(self, backend):
+        """Posts the sends of this rank's first / last owned plane and the receives into its ghost
+        planes; returns the requests.  With the nccl backend the transfers run on the process
+        group's own stream, ordered after the work already queued on the current stream."""
         if self.world == 1:
-            return
+            return []
         dist = self.dist
         send_lo, send_hi, recv_lo, recv_hi = backend.halo_tensors()
         ops = []
@@ -85,9 +90,16 @@ class DistComm:
         if self.rank < self.world - 1:
             ops.append(dist.P2POp(dist.isend, send_hi, self.rank + 1))
             ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
-        for req in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops)
+
+    def exchange_wait(self, backend, reqs):
+        """Orders the current stream (nccl) or the host (gloo) after the transfers."""
+        for req in reqs:
             req.wait()
         backend.halo_commit()
+
+    def exchange(self, backend):
+        self.exchange_wait(backend, self.exchange_start(backend))
 
     def all_sum(self, backend, v):
         if self.world == 1:
@@ -115,6 +127,12 @@ class LocalComm:
             recv_hi.copy_(self.peers[me + 1].backend.halo_tensors()[0])
         backend.halo_commit()
 
+    def exchange_start(self, backend):
+        return []
+
+    def exchange_wait(self, backend, reqs):
+        self.exchange(backend)
+
     def all_sum(self, backend, v):
         raise NotImplementedError("sum over virtual ranks is done by the caller")
 
@@ -135,9 +153,20 @@ class SlabGraph:
     def exchange(self):
         self.comm.exchange(self.backend)
 
+    def _sweep(self, step_time, with_filter):
+        if self.world == 1:
+            if with_filter:
+                self.backend.sweep_and_filter()
+            else:
+                self.backend.sweep(step_time)
+            return
+        reqs = self.comm.exchange_start(self.backend)
+        self.backend.sweep_begin(step_time, with_filter)     # planes that read no ghost plane
+        self.comm.exchange_wait(self.backend, reqs)
+        self.backend.sweep_end()                            # first / last plane, slot rotation
+
     def sweep(self, step_time):
-        self.exchange()
-        self.backend.sweep(step_time)
+        self._sweep(step_time, False)
         return self
 
     def time_filter(self):
@@ -146,10 +175,9 @@ class SlabGraph:
 
     def step(self, nsteps=1):
         for _ in range(nsteps):
-            self.sweep(True)
-            self.sweep(False)
-            self.exchange()
-            self.backend.sweep_and_filter()
+            self._sweep(True, False)
+            self._sweep(False, False)
+            self._sweep(False, True)
         return self
 
     def total_density(self):

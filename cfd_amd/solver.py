@@ -109,6 +109,16 @@ class AdjGraph:
         check(self._lib.cfd_sweep_and_filter(self._h))
         return self
 
+    def sweep_begin(self, step_time, with_filter=False):
+        """First half of a split sweep: the planes that need no ghost plane (see include/cfd_hip.h)."""
+        check(self._lib.cfd_sweep_begin(self._h, 1 if step_time else 0, 1 if with_filter else 0))
+        return self
+
+    def sweep_end(self):
+        """Second half of a split sweep: the planes next to a ghost plane, then the slot rotation."""
+        check(self._lib.cfd_sweep_end(self._h))
+        return self
+
     def total_density(self):
         v = ctypes.c_double()
         check(self._lib.cfd_total_density(self._h, ctypes.byref(v)))

@@ -118,6 +118,18 @@ int cfd_time_filter(cfd_handle *h);
  * src/Main.hs:194-197 with next == 2), in one kernel where the sweep kernel supports it. */
 int cfd_sweep_and_filter(cfd_handle *h);
 
+/* The same sweep (applyDiffEq_adj, src/Main.hs:202-226) in two halves, for a slab that exchanges
+ * ghost planes with its neighbours: cfd_sweep_begin launches every owned plane whose stencil reads
+ * owned planes only (all but the first / last plane where a ghost plane exists), so that the
+ * exchange of the ghost planes can run at the same time on another stream; cfd_sweep_end launches
+ * the remaining planes -- the caller has by then ordered the arrival of the ghost planes before the
+ * handle's stream -- and completes the sweep (slot rotation, currAbsTime).  with_filter != 0 (only
+ * with step_time == 0): followed by correctPrevTime as in cfd_sweep_and_filter.  Between the two
+ * calls every other state-changing entry point returns CFD_E_STATE.  Results are identical to
+ * cfd_sweep / cfd_sweep_and_filter. */
+int cfd_sweep_begin(cfd_handle *h, int step_time, int with_filter);
+int cfd_sweep_end(cfd_handle *h);
+
 /* totalDensity (src/Main.hs:269-270): sum of Density over slot currModTime-1 (owned planes).
  * The reference folds sequentially; this is a tree reduction, so the last bits may differ. */
 int cfd_total_density(cfd_handle *h, double *out);

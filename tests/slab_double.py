@@ -60,6 +60,17 @@ class OracleSlabBackend:
         self.ob.sweep(False)
         self.ob.time_filter()
 
+    # split sweep: the oracle has no partial sweep, so the whole sweep runs at the end -- by which
+    # time the orchestration under test must have delivered the ghost planes
+    def sweep_begin(self, step_time, with_filter=False):
+        self._open = (step_time, with_filter)
+
+    def sweep_end(self):
+        step_time, with_filter = self._open
+        self.ob.sweep(step_time)
+        if with_filter:
+            self.ob.time_filter()
+
     def _own(self, a):
         return a[self.gl * self.plane:(self.gl + self.nx) * self.plane]
 

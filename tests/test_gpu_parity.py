@@ -165,31 +165,45 @@ def test_golden_fixtures_through_c_abi(name):
 
 
 @pytest.mark.parametrize("world,shape", [(2, (40, 33)), (3, (50, 300)), (4, (9, 20))])
-def test_virtual_rank_slabs_match_single_domain(world, shape):
+@pytest.mark.parametrize("split,flags", [(False, 0), (True, 0), (True, 4)])
+def test_virtual_rank_slabs_match_single_domain(world, shape, split, flags):
     """Slab decomposition on one GPU: `world` handles with ghost planes, halo planes copied between
     them as device tensors that alias the library's memory, against the undecomposed run:
-    bit-exact in every owned plane after two steps."""
+    bit-exact in every owned plane after two steps.  split: each sweep as cfd_sweep_begin (planes
+    that need no ghost plane) / exchange / cfd_sweep_end, the order the multi-GPU driver uses, with
+    the filter fused into the third sweep."""
     import torch
     from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
     nx, ny = shape
     params, fields, active = small_case(nx, ny, 1, seed=31)
-    ref = _gpu_graph(params, fields, active, 0)
+    ref = _gpu_graph(params, fields, active, flags)
     ref.step(2)
     peers = []
     for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, nx, ny, world)):
         p = dict(params)
         p["nx"] = x1 - x0
+        p["flags"] = flags
         peers.append(SlabGraph(p, f, a, rank=r, world=world, comm=LocalComm(r, peers)))
     bounds = [nx * r // world for r in range(world + 1)]
     for _ in range(2):
-        for st in (True, False, False):
+        for i, st in enumerate((True, False, False)):
+            if split:
+                for g in peers:
+                    g.backend.sweep_begin(st, i == 2)
+                for g in peers:
+                    g.exchange()
+                torch.cuda.synchronize()
+                for g in peers:
+                    g.backend.sweep_end()
+            else:
+                for g in peers:
+                    g.exchange()
+                torch.cuda.synchronize()
+                for g in peers:
+                    g.backend.sweep(st)
+        if not split:
             for g in peers:
-                g.exchange()
-            torch.cuda.synchronize()
-            for g in peers:
-                g.backend.sweep(st)
-        for g in peers:
-            g.time_filter()
+                g.time_filter()
     total = 0.0
     for r, g in enumerate(peers):
         for rel in range(3):
@@ -250,28 +264,42 @@ def test_golden_fixtures_3d_through_c_abi(name):
         fields = [z["sweep%d_%d" % (i, k)] for k in range(7)]
 
 
-def test_virtual_rank_slabs_3d():
+@pytest.mark.parametrize("split,flags,world", [(False, 0, 3), (True, 0, 3), (True, 4, 3), (True, 4, 10)])
+def test_virtual_rank_slabs_3d(split, flags, world):
+    """3-D slabs on one GPU (world = 10: one plane per slab, no interior at all), whole sweeps or
+    split ones, strict or fast arithmetic: bit-exact against the undecomposed run."""
     import torch
     from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
-    nx, ny, nz, world = 10, 7, 6, 3
+    nx, ny, nz = 10, 7, 6
     params, fields, active = small_case(nx, ny, nz, seed=41)
-    ref = _gpu_graph(params, fields, active, 0)
+    ref = _gpu_graph(params, fields, active, flags)
     ref.step(2)
     peers = []
     for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, nx, ny * nz, world)):
         p = dict(params)
         p["nx"] = x1 - x0
+        p["flags"] = flags
         peers.append(SlabGraph(p, f, a, rank=r, world=world, comm=LocalComm(r, peers)))
     bounds = [nx * r // world for r in range(world + 1)]
     for _ in range(2):
-        for st in (True, False, False):
+        for i, st in enumerate((True, False, False)):
+            if split:
+                for g in peers:
+                    g.backend.sweep_begin(st, i == 2)
+                for g in peers:
+                    g.exchange()
+                torch.cuda.synchronize()
+                for g in peers:
+                    g.backend.sweep_end()
+            else:
+                for g in peers:
+                    g.exchange()
+                torch.cuda.synchronize()
+                for g in peers:
+                    g.backend.sweep(st)
+        if not split:
             for g in peers:
-                g.exchange()
-            torch.cuda.synchronize()
-            for g in peers:
-                g.backend.sweep(st)
-        for g in peers:
-            g.time_filter()
+                g.time_filter()
     pl = ny * nz
     for r, g in enumerate(peers):
         for rel in range(3):
@@ -491,3 +519,14 @@ def test_error_paths():
     g = AdjGraph(params, fields, active)
     with pytest.raises(_capi.CfdError):
         g.read_fields(3)
+    with pytest.raises(_capi.CfdError):
+        g.sweep_end()                       # nothing open
+    with pytest.raises(_capi.CfdError):
+        g.sweep_begin(True, True)           # the filter follows a sweep that does not advance time
+    g.sweep_begin(True)
+    for call in (lambda: g.sweep_begin(False), lambda: g.sweep(True), g.time_filter, g.sweep_and_filter,
+                 lambda: g.step(1)):
+        with pytest.raises(_capi.CfdError):
+            call()
+    g.sweep_end()
+    g.sweep(False)
