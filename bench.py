@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--nx", type=int, default=4096, help="x-planes per GPU")
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--nz", type=int, default=1)
+    ap.add_argument("--case", choices=("synthetic", "cavity"), default="synthetic",
+                    help="cavity: lid-driven-cavity style walls, the global grid is (nx*gpus) x ny (2-D only)")
     ap.add_argument("--arith", choices=("fast", "strict"), default="fast")
     ap.add_argument("--dt", type=float, default=1e-7)
     ap.add_argument("--flags", type=int, default=0, help="extra cfd_params.flags (1 = one-thread-per-cell kernel)")
@@ -110,7 +112,9 @@ def main():
     from cfd_amd.slab import SlabGraph
 
     two_d = a.nz == 1
-    if two_d:
+    if two_d and a.case == "cavity":
+        params, fields, active = cases.cavity_2d_slab(a.nx * world, a.ny, a.nx * rank, a.nx * (rank + 1))
+    elif two_d:
         params, fields, active = cases.synthetic_2d(a.nx, a.ny, seed=1 + rank)
     else:
         params, fields, active = cases.synthetic_3d(a.nx, a.ny, a.nz, seed=3 + rank)
@@ -178,7 +182,8 @@ def main():
     plain_sweeps = 2 * a.steps
     avg_kernel_s = kernel_ms / 1e3 / plain_sweeps
     achieved = cells_per_gpu * bytes_per_update / avg_kernel_s / 1e9
-    workload = ("synthetic_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if two_d else \
+    workload = ("cavity_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if (two_d and a.case == "cavity") else \
+        ("synthetic_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if two_d else \
         ("synthetic_3d %dx%dx%d per GPU" % (a.nx, a.ny, a.nz))
     kernel_name = KERNEL_NAME
     out = {

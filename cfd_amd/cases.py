@@ -107,6 +107,35 @@ def cavity_2d(nx, ny, seed=2, **kw):
     return params, [a.reshape(n) for a in (U, V, W, rho, T, mew, dye)], active.reshape(n)
 
 
+def cavity_2d_slab(nx_global, ny, x0, x1, seed=2, **kw):
+    """Planes x0 .. x1-1 of cavity_2d(nx_global, ny, seed), built without the global arrays (the
+    random stream is advanced to the slab's first value), for one rank of a slab decomposition."""
+    from numpy.random import PCG64, Generator
+    bg = PCG64(seed)
+    bg.advance(x0 * ny)                     # one 64-bit draw per uniform double
+    rng = Generator(bg)
+    sx = x1 - x0
+    n = sx * ny
+    U = np.zeros((sx, ny))
+    U[:, ny - 1] = U0
+    V = np.zeros((sx, ny))
+    W = np.zeros((sx, ny))
+    rho = np.full((sx, ny), RHO0)
+    T = T0 * (1 + 1e-6 * rng.uniform(-1.0, 1.0, (sx, ny)))
+    mew = np.full((sx, ny), MEW0)
+    dye = np.zeros((sx, ny))
+    if x0 <= nx_global // 2 < x1:
+        dye[nx_global // 2 - x0, ny // 2] = 1.0
+    active = np.ones((sx, ny), np.uint8)
+    if x0 == 0:
+        active[0, :] = 0
+    if x1 == nx_global:
+        active[sx - 1, :] = 0
+    active[:, 0] = active[:, ny - 1] = 0
+    params = make_params(sx, ny, 1, REF_DX, REF_DY, REF_DZ, **kw)
+    return params, [a.reshape(n) for a in (U, V, W, rho, T, mew, dye)], active.reshape(n)
+
+
 def synthetic_3d(nx, ny, nz, seed=3, **kw):
     """synthetic_2d's recipe in three dimensions: dz = dx, W = 0.1 u, obstacle spans the middle
     third in z."""

@@ -124,7 +124,10 @@ CFD_HD double half_slope(double up, double vc, double lo) {
 // x/h; with a correctly rounded reciprocal the second then lands on the correctly rounded quotient
 // (Markstein's theorem), i.e. the same bits as the IEEE division the reference performs, at 5
 // multiply-add operations instead of the ~12-instruction division sequence.  Holds for finite x
-// with x/h in the normal range; a zero quotient may lose its sign.
+// with |x| >= 2^-970 or x == 0 (below that the residuals underflow and are no longer exact); a zero
+// quotient may lose its sign.  The numerators it is used on are differences of viscous /
+// conductive products of velocity and temperature scale; the Dye terms, whose numerators do
+// decay into that range, use the plain division.
 CFD_HD double div_by(double x, double h, double rh) {
     const double q0 = x * rh;
     const double q1 = fma(fma(-q0, h, x), rh, q0);
@@ -381,8 +384,10 @@ CFD_HD void phaseB2(const SweepConsts& k, const PhaseA2& C, const ShareX2& XE, c
     }
     // ---- dye
     {
-        r = 0.0 + div_by(XE.gX - X.gX, hx, k.rhx);  r = r + div_by(XW.gX - X.gX, hx, k.rhx);
-        r = r + div_by(YN.gY - Y.gY, hy, k.rhy);    r = r + div_by(YS.gY - Y.gY, hy, k.rhy);
+        // plain divisions: Dye decays towards zero away from its source and these numerators reach
+        // the subnormal range, where div_by is not exact
+        r = 0.0 + (XE.gX - X.gX) / hx;  r = r + (XW.gX - X.gX) / hx;
+        r = r + (YN.gY - Y.gY) / hy;    r = r + (YS.gY - Y.gY) / hy;
         out[E2_DYE] = (r - C.lhs[E2_DYE]) / C.aU[E2_DYE];
     }
 }
@@ -934,10 +939,11 @@ CFD_HD void phaseB3(const SweepConsts& k, const PhaseA3& C, const ShareX3& XP, c
     CROSS(r, ZP, ZM, yMuWV, Hz);  CROSSN(r, ZP, ZM, yMuW, Hz);  CROSSN(r, ZP, ZM, yV, Hz);    // [Mew,W][V] Z Y
     out[E3_T] = (r - C.lhs[E3_T]) / C.aU[E3_T];
     // ---- dye
+    // plain divisions (see the 2-D Dye equation)
     r = 0.0;
-    SAME(r, xp.g, xm.g, cx.g, hx);
-    SAME(r, yp.g, ym.g, cy.g, hy);
-    SAME(r, zp.g, zm.g, cz.g, hz);
+    r = r + (xp.g - cx.g) / hx;  r = r + (xm.g - cx.g) / hx;
+    r = r + (yp.g - cy.g) / hy;  r = r + (ym.g - cy.g) / hy;
+    r = r + (zp.g - cz.g) / hz;  r = r + (zm.g - cz.g) / hz;
     out[E3_DYE] = (r - C.lhs[E3_DYE]) / C.aU[E3_DYE];
 #undef SAME
 #undef SAMEN

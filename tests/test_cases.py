@@ -28,3 +28,15 @@ def test_synthetic_cases_are_seeded_and_shaped():
     assert np.all(fc[0].reshape(20, 20)[:, 19] == 10.0) and np.all(fc[0].reshape(20, 20)[:, :19] == 0)
     p3, f3, a3 = cases.synthetic_3d(10, 8, 6)
     assert f3[2].any() and p3["dz"] == p3["dx"] and f3[0].size == 480
+
+
+def test_cavity_slabs_concatenate_to_the_global_case():
+    from cfd_amd import cases
+    nx, ny = 37, 11
+    _, gf, ga = cases.cavity_2d(nx, ny)
+    for world in (1, 2, 5):
+        bounds = [nx * r // world for r in range(world + 1)]
+        parts = [cases.cavity_2d_slab(nx, ny, bounds[r], bounds[r + 1]) for r in range(world)]
+        for k in range(7):
+            assert np.array_equal(np.concatenate([p[1][k] for p in parts]), gf[k]), (world, k)
+        assert np.array_equal(np.concatenate([p[2] for p in parts]), ga)
