@@ -1,0 +1,16 @@
+# usage: bash scripts/final_profiles.sh <tag>  -- the round's records: default bench, the same command under
+# rocprofv3 --kernel-trace --stats, counter passes for the 2-D and 3-D sweep kernels (separate runs)
+set -e
+TAG=${1:-final}
+O=gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+timeout -k 10 600 python -u bench.py > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+cut -c1-300 $O/bench.json
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py > $O/prof.log 2>&1 || { tail -20 $O/prof.log; exit 1; }
+find $O/prof -name '*kernel_stats.csv' | head -1 | xargs cat > $O/kernel_stats.csv; cat $O/kernel_stats.csv
+bash scripts/pmc.sh $TAG/pmc2d > $O/pmc2d.log 2>&1 || { tail -20 $O/pmc2d.log; exit 1; }
+python3 scripts/pmc_summary.py $TAG/pmc2d > $O/pmc2d_summary.txt
+NZ=256 bash scripts/pmc.sh $TAG/pmc3d > $O/pmc3d.log 2>&1 || { tail -20 $O/pmc3d.log; exit 1; }
+python3 scripts/pmc_summary.py $TAG/pmc3d > $O/pmc3d_summary.txt
+grep -A22 "sweep" $O/pmc2d_summary.txt | head -60
