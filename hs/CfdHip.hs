@@ -46,6 +46,9 @@ foreign import ccall safe "cfd_destroy" c_destroy :: Ptr CfdHandle -> IO ()
 foreign import ccall safe "cfd_step" c_step :: Ptr CfdHandle -> CInt -> IO CInt
 foreign import ccall safe "cfd_sweep" c_sweep :: Ptr CfdHandle -> CInt -> IO CInt
 foreign import ccall safe "cfd_time_filter" c_filter :: Ptr CfdHandle -> IO CInt
+foreign import ccall safe "cfd_sweep_and_filter" c_sweepAndFilter :: Ptr CfdHandle -> IO CInt
+foreign import ccall safe "cfd_sweep_begin" c_sweepBegin :: Ptr CfdHandle -> CInt -> CInt -> IO CInt
+foreign import ccall safe "cfd_sweep_end" c_sweepEnd :: Ptr CfdHandle -> IO CInt
 foreign import ccall safe "cfd_total_density" c_density :: Ptr CfdHandle -> Ptr Double -> IO CInt
 foreign import ccall safe "cfd_read_fields" c_read :: Ptr CfdHandle -> CInt -> Ptr (Ptr Double) -> IO CInt
 foreign import ccall safe "cfd_time" c_time :: Ptr CfdHandle -> Ptr CInt -> Ptr CInt -> IO CInt
