@@ -588,12 +588,20 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     }
 }
 
-// Streaming form of the tiled 2-D sweep (re-associated arithmetic only; an alternative to
-// sweep2d_march2 selected with CFD_VARIANT=20..24, equally fast at 4096 x 4096).  Same tiling and LDS
-// traffic pattern, but a row's phase-A results are turned at once into q, coef and the four
-// pre-scaled neighbour messages (phaseA2s), so the only state a thread carries from row to row is
-// the pending row's q / coef / new Density, the message for the next row's West side, and a ring
-// of RD rows of stored values (RD - 2 rows of prefetch): ~166 registers instead of ~210.
+// Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin by linear id.  This maps the
+// linear id so that the workgroups one XCD receives are consecutive tiles (neighbouring tiles share
+// halo columns / cache lines, which then hit in that L2).  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned orig, unsigned nwg) {
+    const unsigned q = nwg / 8u, r = nwg % 8u, xcd = orig % 8u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + orig / 8u;
+}
+
+// Streaming form of the tiled 2-D sweep (re-associated arithmetic only; the default 2-D kernel for
+// it: 256 threads, 240 stored columns, CFD_VARIANT=20..34 select other shapes).  Same tiling and LDS
+// traffic pattern as sweep2d_march2, but a row's phase-A results are turned at once into q, coef
+// and the four pre-scaled neighbour messages (phaseA2s), so the only state a thread carries from
+// row to row is the pending row's q / coef / new Density, the message for the next row's West side,
+// and a ring of RD rows of stored values (RD - 2 rows of prefetch): ~166 registers instead of ~210.
 // Every row is finished unconditionally (stores that do not belong to the chunk are dropped by an
 // out-of-range offset) and the prologue loads are retired before the loop, which keeps the
 // compiler's vector-memory wait counts exact: a row's stores stay in flight under the next row.
@@ -607,18 +615,28 @@ template <int NT, int MINW, bool FILTER, int RD = 3, int WCOLS = NT - 2>
 __global__ void __launch_bounds__(NT, MINW)
 sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict__ dst,
                const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int ch,
-               const double* __restrict__ fpp, double* __restrict__ fprev) {
+               const double* __restrict__ fpp, double* __restrict__ fprev, int swizzle) {
     __shared__ double lmsg[2][6][NT];
     __shared__ double lraw[2][NF2][NT];
     const int t = threadIdx.x;
-    const int ybase = (int)blockIdx.x * WCOLS - 1;         // column of lane 0 before clamping
-    const int y = ybase + t;
+    // Lane -> column.  Lanes 0 .. WCOLS-1 hold the block's own columns in order, so that with WCOLS a
+    // multiple of 16 every wave's store covers whole, aligned 128-byte lines (a tile that starts one
+    // lane late halves the store bandwidth); lane WCOLS holds the column above the tile, lane
+    // WCOLS+1 the column below it, lanes past that idle.
+    const unsigned wg = swizzle ? xcd_contiguous_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y)
+                                       : blockIdx.x + gridDim.x * blockIdx.y;
+    const int bx = (int)(wg % gridDim.x), by = (int)(wg / gridDim.x);
+    const int ytile = bx * WCOLS;
+    const int y = t < WCOLS ? ytile + t : (t == WCOLS ? ytile + WCOLS : ytile - 1);
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
     const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
-    const int ln = yn - ybase, ls = ys - ybase;             // lanes holding columns yn / ys
-    const int lnc = ln <= NT - 1 ? ln : t, lsc = ls >= 0 ? ls : t;   // outside the block: own value
-    const bool writer = t >= 1 && t <= WCOLS && y < ny;
-    const int xs = x0 + (int)blockIdx.y * ch;
+    auto lane_of = [=](int c) {         // lane that holds column c; outside the tile: this lane (own value)
+        const int r = c - ytile;
+        return r >= 0 && r < WCOLS ? r : (r == WCOLS ? WCOLS : (r == -1 ? WCOLS + 1 : t));
+    };
+    const int lnc = lane_of(yn), lsc = lane_of(ys);
+    const bool writer = t < WCOLS && y < ny;
+    const int xs = x0 + by * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
     // Rows j0 .. xe get a phase A; row xe is the East neighbour of the chunk's last row.  At the end
@@ -1119,6 +1137,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         hipExtLaunchKernelGGL((sweep2d_march<M, NT, MINW, PF>), grid, block, 0, h->stream, ea, eb, \
                               0, KK, src, dst, act, x0, x1, p.ny, xlo, xhi, ch);                     \
     } while (0)
+        static const int swz = getenv("CFD_SWIZZLE") ? atoi(getenv("CFD_SWIZZLE")) : 1;     // XCD-contiguous tile order (tuning knob)
 #define LAUNCH_STREAM(NT, MINW, WC) LAUNCH_STREAM_RD(NT, MINW, WC, 3)
 #define LAUNCH_STREAM_RD(NT, MINW, WC, RDV)                                                         \
     do {                                                                                           \
@@ -1126,15 +1145,15 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         if (fpp)                                                                                   \
             hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, true, RDV, WC>), grid, block, 0,       \
                                   h->stream, ea, eb, 0, h->KF, src, dst, act, x0, x1, p.ny, xlo,     \
-                                  xhi, ch, fpp, fprev);                                            \
+                                  xhi, ch, fpp, fprev, swz);                                       \
         else                                                                                       \
             hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, false, RDV, WC>), grid, block, 0,      \
                                   h->stream, ea, eb, 0, h->KF, src, dst, act, x0, x1, p.ny, xlo,     \
-                                  xhi, ch, fpp, fprev);                                            \
+                                  xhi, ch, fpp, fprev, swz);                                       \
         fused = fpp != nullptr;                                                                    \
     } while (0)
         if (fast) {
-            switch (h->variant < 0 ? 8 : h->variant) {
+            switch (h->variant < 0 ? 30 : h->variant) {
                 case 20: LAUNCH_STREAM(128, 3, 126); break;
                 case 21: LAUNCH_STREAM(128, 2, 126); break;
                 case 22: LAUNCH_STREAM(64, 3, 62); break;
@@ -1145,6 +1164,11 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                 case 27: LAUNCH_STREAM_RD(256, 2, 240, 4); break;
                 case 28: LAUNCH_STREAM_RD(256, 2, 240, 5); break;
                 case 29: LAUNCH_STREAM_RD(128, 2, 112, 5); break;
+                case 30: LAUNCH_STREAM(256, 2, 240); break;
+                case 31: LAUNCH_STREAM(128, 2, 112); break;
+                case 32: LAUNCH_STREAM(192, 2, 176); break;
+                case 33: LAUNCH_STREAM(512, 2, 496); break;
+                case 34: LAUNCH_STREAM(192, 3, 176); break;
                 case 1: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, true); break;
                 case 2: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, false); break;
                 case 3: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, true); break;
@@ -1588,8 +1612,8 @@ const char* cfd_kernel_name(cfd_handle* h) {
         return fast ? "sweep3d_march<fast>" : "sweep3d_march<strict>";
     }
     if (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) return fast ? "sweep2d_simple<fast>" : "sweep2d_simple<strict>";
-    const int v = h->variant < 0 ? 8 : h->variant;
-    if (fast && v >= 20 && v <= 29) return "sweep2d_stream<fast>";
+    const int v = h->variant < 0 ? (fast ? 30 : 8) : h->variant;
+    if (fast && v >= 20 && v <= 34) return "sweep2d_stream<fast>";
     if (v >= 8) return fast ? "sweep2d_march2<fast>" : "sweep2d_march2<strict>";
     return fast ? "sweep2d_march<fast>" : "sweep2d_march<strict>";
 }

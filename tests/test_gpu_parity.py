@@ -311,13 +311,14 @@ def test_virtual_rank_slabs_3d(split, flags, world):
 FAST = 4
 
 
-@pytest.mark.parametrize("kernel_flag", [0, 1])
+@pytest.mark.parametrize("kernel_flag,variant", [(0, -1), (0, 8), (1, -1)])
 @pytest.mark.parametrize("case", ["small", "small_zero_v", "shipped", "synthetic", "cavity"])
-def test_fast_arithmetic_within_1e13_per_sweep(case, kernel_flag):
+def test_fast_arithmetic_within_1e13_per_sweep(case, kernel_flag, variant, monkeypatch):
     """Re-associated arithmetic (CFD_FLAG_FAST_MATH): every sweep, started from the oracle's own
     state, agrees with Oracle B to <= 1e-13 of the field scale (velocity components relative to the
     velocity scale).  Measured on these cases: <= 6e-15."""
     from cfd_amd import cases
+    monkeypatch.setenv("CFD_VARIANT", str(variant))     # -1: default (streamed messages), 8: shared products
     params, fields, active = {
         "small": lambda: small_case(40, 33, 1, 13),
         "small_zero_v": lambda: small_case(31, 17, 1, 2, True),
@@ -410,7 +411,7 @@ def test_tiled_3d_matches_per_cell_3d_bitwise(flags, monkeypatch):
             assert bits_equal(fa[k], fb[k]), (rel, PROPS[k])
 
 
-@pytest.mark.parametrize("variant,chunk", [(20, 32), (21, 5), (22, 1), (23, 32), (24, 7)])
+@pytest.mark.parametrize("variant,chunk", [(-1, 32), (20, 32), (21, 5), (22, 1), (23, 32), (24, 7), (28, 3), (31, 32)])
 @pytest.mark.parametrize("case", ["small", "small_zero_v", "shipped", "cavity"])
 def test_streaming_kernel_within_1e13_per_sweep(case, variant, chunk, monkeypatch):
     """The streaming form of the tiled 2-D kernel (messages instead of shared products) in its launch
@@ -471,9 +472,11 @@ def test_streaming_3d_kernel_shapes_agree_bitwise(monkeypatch):
         assert max(field_errors(outs[0][rel], gs.read_fields(rel))) <= 1e-12
 
 
-def test_fast_tiled_matches_fast_per_cell_bitwise():
-    """Both fast kernels evaluate the same expressions; 1200 x 900, two steps, bit-identical."""
+def test_fast_tiled_matches_fast_per_cell_bitwise(monkeypatch):
+    """The product-sharing tiled kernel and the per-cell kernel evaluate the same fast expressions;
+    1200 x 900, two steps, bit-identical."""
     from cfd_amd import cases
+    monkeypatch.setenv("CFD_VARIANT", "8")
     params, fields, active = cases.synthetic_2d(1200, 900, seed=6)
     ga = _gpu_graph(params, fields, active, FAST)
     gb = _gpu_graph(params, fields, active, FAST | 1)
