@@ -341,6 +341,10 @@ struct PlaneRef {
     __device__ __forceinline__ void st(unsigned voff, unsigned soff, double x) const {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cfd_v2i, x), r, voff, soff, 0);
     }
+    // non-temporal store (written once, not read again by this kernel)
+    __device__ __forceinline__ void st_nt(unsigned voff, unsigned soff, double x) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cfd_v2i, x), r, voff, soff, 2);
+    }
 
 };
 
@@ -677,21 +681,21 @@ sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
         const double nT = stream_finish(pq[S2_T], pcoef[S2_T], me[S2_T], L[2][lnc], L[2][lsc]);
         const double nD = stream_finish(pq[S2_DYE], pcoef[S2_DYE], me[S2_DYE], L[3][lnc], L[3][lsc]);
         const PlaneRef d(dst + (long)x * plane5, pbytes);
-        d.st(vs, (unsigned)F2_RHO * fstride, prho);
-        d.st(vs, (unsigned)F2_T * fstride, nT);
-        d.st(vs, (unsigned)F2_U * fstride, nU);
-        d.st(vs, (unsigned)F2_V * fstride, nV);
-        d.st(vs, (unsigned)F2_DYE * fstride, nD);
+        d.st_nt(vs, (unsigned)F2_RHO * fstride, prho);
+        d.st_nt(vs, (unsigned)F2_T * fstride, nT);
+        d.st_nt(vs, (unsigned)F2_U * fstride, nU);
+        d.st_nt(vs, (unsigned)F2_V * fstride, nV);
+        d.st_nt(vs, (unsigned)F2_DYE * fstride, nD);
         if (FILTER) {
             // Density and Temperature in every cell; U, V, Dye only where the cell is active
             // (coef of U is zero exactly in the cells that keep their values)
             const PlaneRef pv(fprev + (long)x * plane5, pbytes);
             const unsigned vm = pcoef[S2_U] != 0.0 ? vs : 0xFFFFFFF0u;
-            pv.st(vs, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (prho - pp[F2_RHO])));
-            pv.st(vs, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (nT - pp[F2_T])));
-            pv.st(vm, (unsigned)F2_U * fstride, pp[F2_U] + (0.5 * (nU - pp[F2_U])));
-            pv.st(vm, (unsigned)F2_V * fstride, pp[F2_V] + (0.5 * (nV - pp[F2_V])));
-            pv.st(vm, (unsigned)F2_DYE * fstride, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])));
+            pv.st_nt(vs, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (prho - pp[F2_RHO])));
+            pv.st_nt(vs, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (nT - pp[F2_T])));
+            pv.st_nt(vm, (unsigned)F2_U * fstride, pp[F2_U] + (0.5 * (nU - pp[F2_U])));
+            pv.st_nt(vm, (unsigned)F2_V * fstride, pp[F2_V] + (0.5 * (nV - pp[F2_V])));
+            pv.st_nt(vm, (unsigned)F2_DYE * fstride, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])));
         }
     };
     // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw[j&1] holds row j of every lane.
