@@ -899,40 +899,66 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     }
 }
 
-// Streaming form of the tiled 3-D sweep (re-associated arithmetic only): sweep3d_march's tiling with
-// phaseA3s' messages instead of shared products, the row-to-row state of sweep2d_stream (pending q /
-// coef / Density, West message, ring of RD stored rows) and its unconditional row finishing.
-// LDS (dynamic, single-buffered, two barriers per row): 6 stored values + 8 y-message + 9 z-message
-// doubles per thread.
-template <int TY, int TZ, int MINW, int RD = 3>
-__global__ void __launch_bounds__(TY * TZ, MINW)
+// Streaming form of the tiled 3-D sweep (re-associated arithmetic only): phaseA3s' messages instead of
+// shared products, the row-to-row state of sweep2d_stream (pending q / coef / Density, West message,
+// ring of RD stored rows) and its unconditional row finishing.
+// Tile: TYW x TZW own (y, z) columns, lanes along z; threads 0 .. TYW*TZW-1 hold them in order, so with
+// TZW = 16 every 16 lanes store one whole 128-byte line; the threads after them hold the halo ring
+// (row above, row below, column after, column before, four corners -- the corners only feed the
+// slopes of halo cells), the rest idle.  East/West neighbours stay in registers; the four in-plane
+// neighbours' stored values and messages go through LDS (dynamic, single-buffered, two barriers per
+// row): 6 stored values + 8 y-message + 9 z-message doubles per thread.
+template <int TYW, int TZW, int NT, int MINW, int RD = 3>
+__global__ void __launch_bounds__(NT, MINW)
 sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict__ dst,
-               const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi, int ch) {
-    constexpr int NT = TY * TZ;
+               const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi, int ch,
+               int swizzle) {
+    constexpr int NW = TYW * TZW;           // own columns
+    static_assert(NW + 2 * TYW + 2 * TZW + 4 <= NT, "block too small for the tile and its halo ring");
     extern __shared__ double smem[];
     double* const lraw = smem;                  // [NF3][NT]
     double* const lmy = smem + NF3 * NT;        // [8][NT]: ms[0..4], mn[0..2]
     double* const lmz = lmy + 8 * NT;           // [9][NT]: mb[0..4], mt[0..3]
-    const int t = threadIdx.x, tz = t % TZ, ty = t / TZ;
-    const int zbase = (int)blockIdx.x * (TZ - 2) - 1, ybase = (int)blockIdx.y * (TY - 2) - 1;
-    const int y = ybase + ty, z = zbase + tz;
+    const int t = threadIdx.x;
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned wg = swizzle ? xcd_contiguous_id(lin, nwg) : lin;
+    const int bz = (int)(wg % gridDim.x), by = (int)((wg / gridDim.x) % gridDim.y), bxc = (int)(wg / (gridDim.x * gridDim.y));
+    const int ytile = by * TYW, ztile = bz * TZW;
+    // thread -> (row, column) relative to the tile
+    int ry, rz;
+    if (t < NW) { ry = t / TZW; rz = t % TZW; }
+    else if (t < NW + TZW) { ry = TYW; rz = t - NW; }
+    else if (t < NW + 2 * TZW) { ry = -1; rz = t - NW - TZW; }
+    else if (t < NW + 2 * TZW + TYW) { ry = t - NW - 2 * TZW; rz = TZW; }
+    else if (t < NW + 2 * TZW + 2 * TYW) { ry = t - NW - 2 * TZW - TYW; rz = -1; }
+    else { const int c = (t - NW - 2 * TZW - 2 * TYW) & 3; ry = (c & 2) ? -1 : TYW; rz = (c & 1) ? -1 : TZW; }
+    const int y = ytile + ry, z = ztile + rz;
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y), cz = z < 0 ? 0 : (z > nz - 1 ? nz - 1 : z);
-    auto lane_of = [=](int yy, int zz) {        // thread that holds column (yy, zz); outside the tile: this thread
-        const int ly = yy - ybase, lz = zz - zbase;
-        return (ly >= 0 && ly < TY && lz >= 0 && lz < TZ) ? ly * TZ + lz : t;
+    auto lane_of = [=](int yy, int zz) {        // thread that holds column (yy, zz); outside the tile and its ring: this thread
+        const int a = yy - ytile, b = zz - ztile;
+        const bool ain = a >= 0 && a < TYW, bin = b >= 0 && b < TZW;
+        if (ain && bin) return a * TZW + b;
+        if (bin && a == TYW) return NW + b;
+        if (bin && a == -1) return NW + TZW + b;
+        if (ain && b == TZW) return NW + 2 * TZW + a;
+        if (ain && b == -1) return NW + 2 * TZW + TYW + a;
+        if ((a == TYW || a == -1) && (b == TZW || b == -1))
+            return NW + 2 * TZW + 2 * TYW + (a == -1 ? 2 : 0) + (b == -1 ? 1 : 0);
+        return t;
     };
     const int lN = lane_of(cy + 1 > ny - 1 ? ny - 1 : cy + 1, cz), lS = lane_of(cy - 1 < 0 ? 0 : cy - 1, cz);
     const int lT = lane_of(cy, cz + 1 > nz - 1 ? nz - 1 : cz + 1), lB = lane_of(cy, cz - 1 < 0 ? 0 : cz - 1);
-    const bool writer = ty >= 1 && ty <= TY - 2 && tz >= 1 && tz <= TZ - 2 && y < ny && z < nz;
-    const int xs = x0 + (int)blockIdx.z * ch;
+    const bool writer = t < NW && y < ny && z < nz;
+    const int xs = x0 + bxc * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
     const int j1 = xe;      // at the end of the domain row xe is the clamped last row (see sweep2d_stream)
     const long plane = (long)ny * nz, plane6 = (long)NF3 * plane;
     const unsigned pbytes = (unsigned)(plane6 * 8), fstride = (unsigned)(plane * 8);
     const unsigned cell = (unsigned)cy * (unsigned)nz + (unsigned)cz;
-    const unsigned vc = cell * 8u;
-    const unsigned vst = writer ? vc : 0xFFFFFFF0u;
+    const unsigned vc = t < NW + 2 * TZW + 2 * TYW + 4 ? cell * 8u : 0xFFFFFFF0u;   // idle threads load nothing
+    const unsigned vst = writer ? cell * 8u : 0xFFFFFFF0u;
     auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
     auto load_row = [&](int x, double v[NF3]) {
         const PlaneRef p(src + (long)x * plane6, pbytes);
@@ -977,12 +1003,12 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
             const double nD = stream_finish3(pq[S3_DYE], pcoef[S3_DYE], A.me[S3_DYE], lmy[4 * NT + lN], lmy[4 * NT + lS],
                                              lmz[4 * NT + lT], lmz[4 * NT + lB]);
             const PlaneRef d(dst + (long)(x < xlo ? xlo : x) * plane6, pbytes);
-            d.st(vs, (unsigned)F3_RHO * fstride, prho);
-            d.st(vs, (unsigned)F3_T * fstride, nT);
-            d.st(vs, (unsigned)F3_U * fstride, nU);
-            d.st(vs, (unsigned)F3_V * fstride, nV);
-            d.st(vs, (unsigned)F3_W * fstride, nW);
-            d.st(vs, (unsigned)F3_DYE * fstride, nD);
+            d.st_nt(vs, (unsigned)F3_RHO * fstride, prho);
+            d.st_nt(vs, (unsigned)F3_T * fstride, nT);
+            d.st_nt(vs, (unsigned)F3_U * fstride, nU);
+            d.st_nt(vs, (unsigned)F3_V * fstride, nV);
+            d.st_nt(vs, (unsigned)F3_W * fstride, nW);
+            d.st_nt(vs, (unsigned)F3_DYE * fstride, nD);
         }
         __syncthreads();        // every read of row j's stored values and row j-1's messages is done
 #pragma unroll
@@ -1229,35 +1255,35 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, KK, src, dst, act,     \
                               x0, x1, p.ny, p.nz, xlo, xhi, ch);                                     \
     } while (0)
-#define LAUNCH_STREAM3(TY, TZ, MINW, RDV)                                                           \
+#define LAUNCH_STREAM3(TYW, TZW, NT, MINW, RDV)                                                     \
     do {                                                                                           \
-        auto kern = sweep3d_stream<TY, TZ, MINW, RDV>;                                             \
-        const size_t lds = (size_t)(NF3 + 8 + 9) * TY * TZ * sizeof(double);                       \
+        auto kern = sweep3d_stream<TYW, TZW, NT, MINW, RDV>;                                       \
+        const size_t lds = (size_t)(NF3 + 8 + 9) * NT * sizeof(double);                            \
         static bool attr_set[64] = {};                                                             \
         if (lds > 64 * 1024 && !attr_set[h->device & 63]) {                                        \
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                \
             attr_set[h->device & 63] = true;                                                       \
         }                                                                                          \
-        dim3 block(TY * TZ), grid((p.nz + TZ - 3) / (TZ - 2), (p.ny + TY - 3) / (TY - 2),          \
-                                  (x1 - x0 + ch - 1) / ch);                                           \
+        dim3 block(NT), grid((p.nz + TZW - 1) / TZW, (p.ny + TYW - 1) / TYW, (x1 - x0 + ch - 1) / ch); \
         hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, h->KF, src, dst, act,  \
-                              x0, x1, p.ny, p.nz, xlo, xhi, ch);                                     \
+                              x0, x1, p.ny, p.nz, xlo, xhi, ch, swz3);                             \
     } while (0)
+        static const int swz3 = getenv("CFD_SWIZZLE") ? atoi(getenv("CFD_SWIZZLE")) : 1;
         if (fast) {
             switch (h->variant < 0 ? 0 : h->variant) {
-                case 11: LAUNCH_STREAM3(16, 16, 1, 3); break;
-                case 12: LAUNCH_STREAM3(8, 32, 2, 3); break;
-                case 13: LAUNCH_STREAM3(16, 32, 1, 3); break;
-                case 14: LAUNCH_STREAM3(16, 16, 2, 4); break;
-                case 15: LAUNCH_STREAM3(8, 16, 2, 3); break;
-                case 16: LAUNCH_STREAM3(16, 32, 2, 3); break;
+                case 11: LAUNCH_STREAM3(12, 16, 256, 1, 3); break;
+                case 12: LAUNCH_STREAM3(5, 32, 256, 2, 3); break;
+                case 13: LAUNCH_STREAM3(14, 14, 256, 2, 3); break;      // the unaligned 14 x 14 tile
+                case 14: LAUNCH_STREAM3(12, 16, 256, 2, 4); break;
+                case 15: LAUNCH_STREAM3(4, 16, 128, 2, 3); break;
+                case 16: LAUNCH_STREAM3(26, 16, 512, 2, 3); break;
                 case 1: LAUNCH_MARCH3(MathFast3, h->KF, 8, 32, 2); break;
                 case 2: LAUNCH_MARCH3(MathFast3, h->KF, 16, 32, 1); break;
                 case 3: LAUNCH_MARCH3(MathFast3, h->KF, 8, 16, 2); break;
                 case 4: LAUNCH_MARCH3(MathFast3, h->KF, 16, 16, 2); break;
                 case 5: LAUNCH_MARCH3(MathFast3, h->KF, 16, 16, 1); break;
-                default: LAUNCH_STREAM3(16, 16, 2, 3); break;
+                default: LAUNCH_STREAM3(12, 16, 256, 2, 3); break;
             }
         } else {
             switch (h->variant < 0 ? 0 : h->variant) {
