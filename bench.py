@@ -42,8 +42,8 @@ SWEEPS_PER_STEP = 3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nx", type=int, default=4096, help="x-planes per GPU")
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--nz", type=int, default=1)
@@ -177,9 +177,9 @@ def main():
     del fields
     updates = cells_per_gpu * world * SWEEPS_PER_STEP * a.steps
     bytes_per_update = BYTES_PER_UPDATE_2D if two_d else BYTES_PER_UPDATE_3D
-    # plain (unfused) sweeps in the timed region: two per step.  At N > 1 each of them is two or three
+    # plain (unfused) sweeps in the timed region: two per step (three where the kernel does not fuse the filter).  At N > 1 each of them is two or three
     # launches (interior planes, then the planes next to a ghost plane); their times are summed.
-    plain_sweeps = 2 * a.steps
+    plain_sweeps = (2 if fused_launches else 3) * a.steps       # the third sweep of a step is timed as "fused" where it is
     avg_kernel_s = kernel_ms / 1e3 / plain_sweeps
     achieved = cells_per_gpu * bytes_per_update / avg_kernel_s / 1e9
     workload = ("cavity_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if (two_d and a.case == "cavity") else \

@@ -908,11 +908,12 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
 // slopes of halo cells), the rest idle.  East/West neighbours stay in registers; the four in-plane
 // neighbours' stored values and messages go through LDS (dynamic, single-buffered, two barriers per
 // row): 6 stored values + 8 y-message + 9 z-message doubles per thread.
-template <int TYW, int TZW, int NT, int MINW, int RD = 3>
+// FILTER: the sweep that ends a step also applies the time filter to the values it has just computed.
+template <int TYW, int TZW, int NT, int MINW, bool FILTER, int RD = 3>
 __global__ void __launch_bounds__(NT, MINW)
 sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict__ dst,
                const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi, int ch,
-               int swizzle) {
+               int swizzle, const double* __restrict__ fpp, double* __restrict__ fprev) {
     constexpr int NW = TYW * TZW;           // own columns
     static_assert(NW + 2 * TYW + 2 * TZW + 4 <= NT, "block too small for the tile and its halo ring");
     extern __shared__ double smem[];
@@ -978,6 +979,13 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
         for (int f = 0; f < NF3; ++f) h[0][f] = half_slope(Re[f], Rc[f], Rw[f]);
         load_row(clampx(j + RD - 1), Rw);
         const unsigned char act_n = load_act(clampx(j + 1));
+        double pp[NF3];
+        if (FILTER) {   // stored values of row j-1 in slot t-2, issued early, consumed when the row is finished
+            const int xr = j - 1 < xs ? xs : j - 1;
+            const PlaneRef q(fpp + (long)xr * plane6, pbytes);
+#pragma unroll
+            for (int f = 0; f < NF3; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
+        }
 #pragma unroll
         for (int f = 0; f < NF3; ++f) {
             h[1][f] = half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS]);
@@ -1009,6 +1017,18 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
             d.st_nt(vs, (unsigned)F3_V * fstride, nV);
             d.st_nt(vs, (unsigned)F3_W * fstride, nW);
             d.st_nt(vs, (unsigned)F3_DYE * fstride, nD);
+            if (FILTER) {
+                // Density and Temperature in every cell; U, V, W, Dye only where the cell is active
+                // (coef of U is zero exactly in the cells that keep their values)
+                const PlaneRef pv(fprev + (long)(x < xlo ? xlo : x) * plane6, pbytes);
+                const unsigned vm = pcoef[S3_U] != 0.0 ? vs : 0xFFFFFFF0u;
+                pv.st_nt(vs, (unsigned)F3_RHO * fstride, pp[F3_RHO] + (0.5 * (prho - pp[F3_RHO])));
+                pv.st_nt(vs, (unsigned)F3_T * fstride, pp[F3_T] + (0.5 * (nT - pp[F3_T])));
+                pv.st_nt(vm, (unsigned)F3_U * fstride, pp[F3_U] + (0.5 * (nU - pp[F3_U])));
+                pv.st_nt(vm, (unsigned)F3_V * fstride, pp[F3_V] + (0.5 * (nV - pp[F3_V])));
+                pv.st_nt(vm, (unsigned)F3_W * fstride, pp[F3_W] + (0.5 * (nW - pp[F3_W])));
+                pv.st_nt(vm, (unsigned)F3_DYE * fstride, pp[F3_DYE] + (0.5 * (nD - pp[F3_DYE])));
+            }
         }
         __syncthreads();        // every read of row j's stored values and row j-1's messages is done
 #pragma unroll
@@ -1257,17 +1277,19 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
     } while (0)
 #define LAUNCH_STREAM3(TYW, TZW, NT, MINW, RDV)                                                     \
     do {                                                                                           \
-        auto kern = sweep3d_stream<TYW, TZW, NT, MINW, RDV>;                                       \
+        auto kern = fpp ? sweep3d_stream<TYW, TZW, NT, MINW, true, RDV>                            \
+                        : sweep3d_stream<TYW, TZW, NT, MINW, false, RDV>;                          \
         const size_t lds = (size_t)(NF3 + 8 + 9) * NT * sizeof(double);                            \
-        static bool attr_set[64] = {};                                                             \
-        if (lds > 64 * 1024 && !attr_set[h->device & 63]) {                                        \
+        static bool attr_set[2][64] = {};                                                          \
+        if (lds > 64 * 1024 && !attr_set[fpp ? 1 : 0][h->device & 63]) {                           \
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                \
-            attr_set[h->device & 63] = true;                                                       \
+            attr_set[fpp ? 1 : 0][h->device & 63] = true;                                          \
         }                                                                                          \
         dim3 block(NT), grid((p.nz + TZW - 1) / TZW, (p.ny + TYW - 1) / TYW, (x1 - x0 + ch - 1) / ch); \
         hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, h->KF, src, dst, act,  \
-                              x0, x1, p.ny, p.nz, xlo, xhi, ch, swz3);                             \
+                              x0, x1, p.ny, p.nz, xlo, xhi, ch, swz3, fpp, fprev);                 \
+        fused = fpp != nullptr;                                                                    \
     } while (0)
         static const int swz3 = getenv("CFD_SWIZZLE") ? atoi(getenv("CFD_SWIZZLE")) : 1;
         if (fast) {

@@ -83,11 +83,12 @@ def test_single_sweep_vs_libm_pow_form():
         assert rel_err(fg[k], f0[k]) <= 1e-13, PROPS[k]
 
 
-@pytest.mark.parametrize("flags", [0, 4])
-def test_fused_filter_equals_separate_filter(flags):
-    """cfd_step (filter fused into the third sweep) against sweep, sweep, sweep, filter launched
-    separately: bit-identical in all three slots, for both arithmetic forms."""
-    params, fields, active = small_case(70, 300, 1, 17)
+@pytest.mark.parametrize("flags,shape", [(0, (70, 300, 1)), (4, (70, 300, 1)), (4, (37, 29, 35)), (0, (12, 9, 7))])
+def test_fused_filter_equals_separate_filter(flags, shape):
+    """cfd_step (filter fused into the third sweep where the kernel supports it) against sweep, sweep,
+    sweep, filter launched separately: bit-identical in all three slots, for both arithmetic forms,
+    2-D and 3-D."""
+    params, fields, active = small_case(shape[0], shape[1], shape[2], 17)
     ga = _gpu_graph(params, fields, active, flags)
     gb = _gpu_graph(params, fields, active, flags)
     for step in range(4):
