@@ -411,6 +411,7 @@ struct FastConsts {
     double kxym, kxzm, kyzm;    // m23 * kxy, ...
     double lambda, suth, R, cv, rcv, k, dyef;
     double c83h, c83n;
+    double cp;              // cv + R (streaming forms: convective + pressure-work energy flux in one product)
     // streaming form (2-D): centre coefficients and Dye constants with the Dye factor folded in
     double cUa, cVb;        // 2 (kxxm + kyy), 2 (kxx + kyym)
     double kxx2, kyy2;      // 2 kxx, 2 kyy
@@ -429,6 +430,7 @@ inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy, d
     f.kxym = c.m23 * f.kxy;  f.kxzm = c.m23 * f.kxz;  f.kyzm = c.m23 * f.kyz;
     f.lambda = c.lambda; f.suth = c.suth; f.R = c.R; f.cv = c.cv; f.rcv = 1.0 / c.cv; f.k = c.k; f.dyef = c.dyef;
     f.c83h = c.c83h; f.c83n = c.c83n;
+    f.cp = c.cv + c.R;
     f.cUa = 2.0 * (f.kxxm + f.kyy);  f.cVb = 2.0 * (f.kxx + f.kyym);
     f.kxx2 = 2.0 * f.kxx;  f.kyy2 = 2.0 * f.kyy;
     f.kxxd = c.dyef * f.kxx;  f.kyyd = c.dyef * f.kyy;  f.cDg = 2.0 * (f.kxxd + f.kyyd);
@@ -583,13 +585,14 @@ enum { S2_U = 0, S2_V, S2_T, S2_DYE };
 
 CFD_HD double mu_stream(const FastConsts& k, double t) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // lambda t^1.5 / (t + S) = lambda t^2 / sqrt(t (t + S)^2): one reciprocal-square-root estimate and
+    // one Newton correction of it
     const double z = t + k.suth;
-    const double y = __builtin_amdgcn_rsq(t), r = __builtin_amdgcn_rcp(z);
-    const double g = t * y;                         // ~ sqrt(t), relative error d
-    const double d2 = fma(-g, y, 1.0);              // 2 d
-    const double e = fma(-z, r, 1.0);               // relative error of r
-    const double base = ((k.lambda * t) * g) * r;
-    return fma(base, fma(0.5, d2, e), base);
+    const double p = t * (z * z);
+    const double y = __builtin_amdgcn_rsq(p);
+    const double d2 = fma(-(p * y), y, 1.0);        // 1 - p y^2 = twice the relative error of y
+    const double base = (k.lambda * t) * (t * y);
+    return fma(base, 0.5 * d2, base);
 #else
     return (k.lambda * t) * (sqrt(t) / (t + k.suth));
 #endif
@@ -617,7 +620,7 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     div[E2_RHO] = k.rcx * (mE - mW);
     div[E2_U] = k.rcx * ((mE * fE[F2_U] - mW * fW[F2_U]) + (pE - pW));
     div[E2_V] = k.rcx * (mE * fE[F2_V] - mW * fW[F2_V]);
-    div[E2_T] = k.rcx * (k.cv * (mE * fE[F2_T] - mW * fW[F2_T]) + (pE * fE[F2_U] - pW * fW[F2_U]));
+    div[E2_T] = k.rcx * (k.cp * (mE * fE[F2_T] - mW * fW[F2_T]));       // cv m T + p u = (cv + R) m T
     div[E2_DYE] = k.rcx * (mE * fE[F2_DYE] - mW * fW[F2_DYE]);
     const double dea = muE * fE[F2_U] - muW * fW[F2_U], deb = muE * fE[F2_V] - muW * fW[F2_V];
     // ---- y faces
@@ -632,7 +635,7 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     div[E2_RHO] = fma(k.rcy, mN - mS, div[E2_RHO]);
     div[E2_U] = fma(k.rcy, mN * fN[F2_U] - mS * fS[F2_U], div[E2_U]);
     div[E2_V] = fma(k.rcy, (mN * fN[F2_V] - mS * fS[F2_V]) + (pN - pS), div[E2_V]);
-    div[E2_T] = fma(k.rcy, k.cv * (mN * fN[F2_T] - mS * fS[F2_T]) + (pN * fN[F2_V] - pS * fS[F2_V]), div[E2_T]);
+    div[E2_T] = fma(k.rcy, k.cp * (mN * fN[F2_T] - mS * fS[F2_T]), div[E2_T]);
     div[E2_DYE] = fma(k.rcy, mN * fN[F2_DYE] - mS * fS[F2_DYE], div[E2_DYE]);
     const double aN = muN * fN[F2_U], aS = muS * fS[F2_U];
     const double dna = aN - aS, dnb = muN * fN[F2_V] - muS * fS[F2_V];
@@ -1117,7 +1120,7 @@ CFD_HD void phaseA3s(const FastConsts& k, const double c[NF3], const double h[3]
             if (cc == d) dd = dd + (pU - pL);
             div[E3_U + cc] = fma(rc[d], dd, div[E3_U + cc]);
         }
-        div[E3_T] = fma(rc[d], k.cv * (mU * fu[F3_T] - mL * fl[F3_T]) + (pU * fu[F3_U + d] - pL * fl[F3_U + d]), div[E3_T]);
+        div[E3_T] = fma(rc[d], k.cp * (mU * fu[F3_T] - mL * fl[F3_T]), div[E3_T]);     // cv m T + p u = (cv + R) m T
         div[E3_DYE] = fma(rc[d], mU * fu[F3_DYE] - mL * fl[F3_DYE], div[E3_DYE]);
         double au[3], al[3];
         for (int q = 0; q < 3; ++q) { au[q] = muU * fu[F3_U + q]; al[q] = muL * fl[F3_U + q]; dmu[d][q] = au[q] - al[q]; }
