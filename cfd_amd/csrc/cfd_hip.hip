@@ -322,6 +322,14 @@ sweep3d_simple(typename M::Consts K, const double* __restrict__ src, double* __r
     dp[(long)F3_DYE * plane] = act ? o[E3_DYE] : sp[(long)F3_DYE * plane];
 }
 
+// Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin by linear id.  This maps the
+// linear id so that the workgroups one XCD receives are consecutive tiles (neighbouring tiles share
+// halo columns / cache lines, which then hit in that L2).  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned orig, unsigned nwg) {
+    const unsigned q = nwg / 8u, r = nwg % 8u, xcd = orig % 8u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + orig / 8u;
+}
+
 // Buffer-resource addressing: one 128-bit descriptor per x-plane (built from block-uniform values,
 // so it lives in scalar registers), a per-lane 32-bit byte offset for the column, and a scalar
 // byte offset for the field.  No per-lane 64-bit address arithmetic; an out-of-range per-lane
@@ -467,7 +475,7 @@ sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __re
 //     retires the West row, and the load of row j+2 is issued straight into its registers.
 //   * FILTER: the sweep that ends a step also applies the time filter (correctPrevTime) to the
 //     values it has just computed: prev <- pp + 0.5*(new - pp), so the new slot is not read back.
-template <class M, int NT, int MINW, bool FILTER>
+template <class M, int NT, int MINW, bool FILTER, int WCOLS = NT - 2>
 __global__ void __launch_bounds__(NT, MINW)
 sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
                const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int ch,
@@ -475,21 +483,28 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     __shared__ double lds[2][M::NSY][NT];
     __shared__ double lraw[2][NF2][NT];
     const int t = threadIdx.x;
-    const int ybase = (int)blockIdx.x * (NT - 2) - 1;      // column of lane 0 before clamping
-    const int y = ybase + t;
+    // Lanes 0 .. WCOLS-1 hold the block's own columns in order (with WCOLS a multiple of 16 every
+    // wave's store covers whole 128-byte lines), lane WCOLS the column above the tile, lane WCOLS+1
+    // the column below it; lanes past that idle.  Tiles are taken in XCD-contiguous order.
+    const unsigned wg = xcd_contiguous_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int bx = (int)(wg % gridDim.x), by = (int)(wg / gridDim.x);
+    const int ytile = bx * WCOLS;
+    const int y = t < WCOLS ? ytile + t : (t == WCOLS ? ytile + WCOLS : ytile - 1);
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
     const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
-    // lane that holds column yn / ys (lane l holds column clamp(ybase + l))
-    const int ln = yn - ybase, ls = ys - ybase;
-    const int lnc = ln <= NT - 1 ? ln : t, lsc = ls >= 0 ? ls : t;   // outside the block: own value
-    const bool writer = t >= 1 && t <= NT - 2 && y < ny;
-    const int xs = x0 + (int)blockIdx.y * ch;
+    auto lane_of = [=](int c) {         // lane that holds column c; outside the tile: this lane (own value)
+        const int r = c - ytile;
+        return r >= 0 && r < WCOLS ? r : (r == WCOLS ? WCOLS : (r == -1 ? WCOLS + 1 : t));
+    };
+    const int lnc = lane_of(yn), lsc = lane_of(ys);
+    const bool writer = t < WCOLS && y < ny;
+    const int xs = x0 + by * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
     const int j1 = xe < xhi ? xe : xhi;
     const long plane5 = (long)NF2 * ny;
     const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
-    const unsigned vc = (unsigned)cy * 8u;
+    const unsigned vc = t <= WCOLS + 1 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // lanes past the tile load nothing
     const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
     auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
     auto load_row = [&](int x, unsigned voff, double v[NF2]) {
@@ -514,9 +529,8 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW,
                     const double pp[NF2]) {
         typename M::SY YN, YS;
-        const int tn = t + 1 > NT - 1 ? NT - 1 : t + 1, tsn = t - 1 < 0 ? 0 : t - 1;
-        M::get_sy(&lds[x & 1][0][tn], NT, YN);
-        M::get_sy(&lds[x & 1][0][tsn], NT, YS);
+        M::get_sy(&lds[x & 1][0][lnc], NT, YN);
+        M::get_sy(&lds[x & 1][0][lsc], NT, YS);
         double o[5];
         M::phaseB(K, C, XE, XW, YN, YS, o);
         const bool act = act_c != 0;
@@ -524,20 +538,20 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         const double nU = select(am, o[E2_U], M::own(C, 0)), nV = select(am, o[E2_V], M::own(C, 1)),
                      nD = select(am, o[E2_DYE], M::own(C, 2));
         const PlaneRef d(dst + (long)x * plane5, pbytes);
-        d.st(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
-        d.st(vst, (unsigned)F2_T * fstride, o[E2_T]);
-        d.st(vst, (unsigned)F2_U * fstride, nU);
-        d.st(vst, (unsigned)F2_V * fstride, nV);
-        d.st(vst, (unsigned)F2_DYE * fstride, nD);
+        d.st_nt(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
+        d.st_nt(vst, (unsigned)F2_T * fstride, o[E2_T]);
+        d.st_nt(vst, (unsigned)F2_U * fstride, nU);
+        d.st_nt(vst, (unsigned)F2_V * fstride, nV);
+        d.st_nt(vst, (unsigned)F2_DYE * fstride, nD);
         if (FILTER) {
             // Density and Temperature in every cell; U, V, Dye only where the cell is active
             const PlaneRef pv(fprev + (long)x * plane5, pbytes);
             const unsigned vm = act ? vst : 0xFFFFFFF0u;
-            pv.st(vst, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (o[E2_RHO] - pp[F2_RHO])));
-            pv.st(vst, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (o[E2_T] - pp[F2_T])));
-            pv.st(vm, (unsigned)F2_U * fstride, pp[F2_U] + (0.5 * (nU - pp[F2_U])));
-            pv.st(vm, (unsigned)F2_V * fstride, pp[F2_V] + (0.5 * (nV - pp[F2_V])));
-            pv.st(vm, (unsigned)F2_DYE * fstride, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])));
+            pv.st_nt(vst, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (o[E2_RHO] - pp[F2_RHO])));
+            pv.st_nt(vst, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (o[E2_T] - pp[F2_T])));
+            pv.st_nt(vm, (unsigned)F2_U * fstride, pp[F2_U] + (0.5 * (nU - pp[F2_U])));
+            pv.st_nt(vm, (unsigned)F2_V * fstride, pp[F2_V] + (0.5 * (nV - pp[F2_V])));
+            pv.st_nt(vm, (unsigned)F2_DYE * fstride, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])));
         }
     };
     // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw[j&1] holds row j of every lane.
@@ -590,14 +604,6 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, pp);
         else emit(xe - 1, P2, P2.sx, P1.sx, pp);
     }
-}
-
-// Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin by linear id.  This maps the
-// linear id so that the workgroups one XCD receives are consecutive tiles (neighbouring tiles share
-// halo columns / cache lines, which then hit in that L2).  Bijective for any grid size.
-__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned orig, unsigned nwg) {
-    const unsigned q = nwg / 8u, r = nwg % 8u, xcd = orig % 8u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + orig / 8u;
 }
 
 // Streaming form of the tiled 2-D sweep (re-associated arithmetic only; the default 2-D kernel for
@@ -1168,15 +1174,16 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                                   act, x0, x1, p.ny, xlo, xhi);
     } else if (h->two_d) {
         const int ch = h->chunk;
-#define LAUNCH_MARCH2(M, KK, NT, MINW)                                                              \
+#define LAUNCH_MARCH2(M, KK, NT, MINW) LAUNCH_MARCH2W(M, KK, NT, MINW, (NT - 2))
+#define LAUNCH_MARCH2W(M, KK, NT, MINW, WC)                                                         \
     do {                                                                                           \
-        dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (x1 - x0 + ch - 1) / ch);                    \
+        dim3 block(NT), grid((p.ny + WC - 1) / WC, (x1 - x0 + ch - 1) / ch);                       \
         if (fpp)                                                                                   \
-            hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW, true>), grid, block, 0, h->stream,  \
+            hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW, true, WC>), grid, block, 0, h->stream, \
                                   ea, eb, 0, KK, src, dst, act, x0, x1, p.ny, xlo, xhi, ch, fpp,     \
                                   fprev);                                                          \
         else                                                                                       \
-            hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW, false>), grid, block, 0, h->stream, \
+            hipExtLaunchKernelGGL((sweep2d_march2<M, NT, MINW, false, WC>), grid, block, 0, h->stream, \
                                   ea, eb, 0, KK, src, dst, act, x0, x1, p.ny, xlo, xhi, ch, fpp,     \
                                   fprev);                                                          \
         fused = fpp != nullptr;                                                                    \
@@ -1243,11 +1250,16 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                 case 9: LAUNCH_MARCH2(MathStrict2, h->K, 128, 2); break;
                 case 10: LAUNCH_MARCH2(MathStrict2, h->K, 256, 2); break;
                 case 12: LAUNCH_MARCH2(MathStrict2, h->K, 256, 1); break;
+                case 13: LAUNCH_MARCH2W(MathStrict2, h->K, 256, 1, 240); break;
+                case 14: LAUNCH_MARCH2W(MathStrict2, h->K, 128, 1, 112); break;
+                case 15: LAUNCH_MARCH2W(MathStrict2, h->K, 256, 2, 240); break;
+                case 16: LAUNCH_MARCH2W(MathStrict2, h->K, 192, 1, 176); break;
                 default: LAUNCH_MARCH(MathStrict2, h->K, 256, 2, false); break;
             }
         }
 #undef LAUNCH_MARCH
 #undef LAUNCH_MARCH2
+#undef LAUNCH_MARCH2W
 #undef LAUNCH_STREAM
 #undef LAUNCH_STREAM_RD
     } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant < 0)) {
