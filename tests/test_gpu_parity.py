@@ -506,6 +506,23 @@ def test_strict_bit_exact_with_subnormal_dye(scale, nz, flags):
     _assert_slots_bit_equal(g, b, "subnormal dye")
 
 
+def test_rccl_transport_on_aliased_halo_planes():
+    """The transport the multi-GPU driver uses, as far as one GPU allows: a process group with the nccl
+    (RCCL) backend, world size 1; the halo planes of a slab handle -- torch tensors that alias the
+    library's device memory -- are exchanged with the rank itself through batch_isend_irecv, once
+    synchronously and once with the interior sweep launched between posting and waiting, then an
+    all-reduce.  Run in a child process (own process group).  tests/rccl_self.py prints the checks."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "rccl_self.py")], capture_output=True, text=True,
+                         timeout=110)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "after first exchange: True" in out.stdout, out.stdout
+    assert "second exchange ok: True" in out.stdout and "finite after sweep: True" in out.stdout, out.stdout
+
+
 def test_compiled_host_prints_reference_stdout():
     """driver/cfd_main (C++ over the C ABI, no Python in the loop) runs the shipped case for five
     steps and prints the same blocks as the golden transcript (generated by the literal oracle)."""
