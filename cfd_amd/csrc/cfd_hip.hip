@@ -356,125 +356,26 @@ struct PlaneRef {
 
 };
 
-// Tiled sweep ("march"): a block owns NT-2 adjacent columns (lanes run along y, the contiguous
-// index) plus one halo column on each side, and walks a chunk of x-planes.  Each thread keeps
-// its column's phase-A results for rows x-1, x, x+1 in registers, so the East/West neighbour
-// products never leave the thread; the North/South neighbour products of the current row cross
-// lanes through a double-buffered LDS tile.  Phase A is evaluated exactly once per cell (plus
-// the two halo columns and two extra rows per chunk), and every cell is read from HBM once.
-//
-//   iteration j:  issue the loads the NEXT iteration needs (row j+2, N/S of row j+1, mask of row j)
-//                 phase A of row j  ->  publish its y-products in lds[j&1]
-//                 phase B of row j-1 (centre = row j-1, East = row j, West = row j-2,
-//                                     North/South = lds[(j-1)&1] of lanes t+1 / t-1)
-//                 one barrier
-template <class M, int NT, int MINW, bool PREFETCH>
-__global__ void __launch_bounds__(NT, MINW)
-sweep2d_march(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
-              const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int ch) {
-    __shared__ double lds[2][M::NSY][NT];
-    const int t = threadIdx.x;
-    const int y = (int)blockIdx.x * (NT - 2) - 1 + t;
-    const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
-    const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
-    const bool writer = t >= 1 && t <= NT - 2 && y < ny;
-    const int xs = x0 + (int)blockIdx.y * ch;
-    const int xe = xs + ch < nx ? xs + ch : nx;
-    const int j0 = xs - 1 > xlo ? xs - 1 : xlo;      // first and last row whose phase A is needed
-    const int j1 = xe < xhi ? xe : xhi;
-    const long plane5 = (long)NF2 * ny;
-    const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
-    const unsigned vc = (unsigned)cy * 8u, vn = (unsigned)yn * 8u, vs = (unsigned)ys * 8u;
-    const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
-    auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
-    auto load_row = [&](int x, unsigned voff, double v[NF2]) {
-        const PlaneRef p(src + (long)x * plane5, pbytes);
-#pragma unroll
-        for (int f = 0; f < NF2; ++f) v[f] = p.ld(voff, (unsigned)f * fstride);
-    };
-    auto load_act = [&](int x) { return PlaneRef(active + (long)x * ny, (unsigned)ny).ldb((unsigned)cy); };
-
-    double rw[NF2], rc[NF2], re[NF2], rn[NF2], rs[NF2];
-    load_row(clampx(j0 - 1), vc, rw);
-    load_row(j0, vc, rc);
-    load_row(clampx(j0 + 1), vc, re);
-    load_row(j0, vn, rn);
-    load_row(j0, vs, rs);
-
-    // Phase-A results of three consecutive rows rotate through P0, P1, P2 (the loop is unrolled by
-    // three so that the roles "row j", "row j-1", "row j-2" are fixed per copy and nothing is moved).
-    typename M::PA P0, P1, P2;
-    unsigned char act_c = 1;    // mask of row j-1
-
-    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW) {
-        // phase B of row x; C holds its phase A, lds[x&1] its neighbours' y-products
-        typename M::SY YN, YS;
-        const int tn = t + 1 > NT - 1 ? NT - 1 : t + 1, tsn = t - 1 < 0 ? 0 : t - 1;
-        M::get_sy(&lds[x & 1][0][tn], NT, YN);
-        M::get_sy(&lds[x & 1][0][tsn], NT, YS);
-        double o[5];
-        M::phaseB(K, C, XE, XW, YN, YS, o);
-        const bool act = act_c != 0;
-        const PlaneRef d(dst + (long)x * plane5, pbytes);
-        d.st(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
-        d.st(vst, (unsigned)F2_T * fstride, o[E2_T]);
-        d.st(vst, (unsigned)F2_U * fstride, act ? o[E2_U] : M::own(C, 0));
-        d.st(vst, (unsigned)F2_V * fstride, act ? o[E2_V] : M::own(C, 1));
-        d.st(vst, (unsigned)F2_DYE * fstride, act ? o[E2_DYE] : M::own(C, 2));
-    };
-    // one row: phase A of row j into An, then phase B of row j-1 (centre Ac, West Aw)
-    auto row = [&](int j, typename M::PA& An, const typename M::PA& Ac, const typename M::PA& Aw, bool first) {
-        double re2[NF2], rn2[NF2], rs2[NF2];
-        const int jn = clampx(j + 1);
-        load_row(clampx(j + 2), vc, re2);
-        load_row(jn, vn, rn2);
-        load_row(jn, vs, rs2);
-        const unsigned char act_n = load_act(j);
-        double hx[NF2];
-        x_half_slopes2(rc, re, rw, hx);
-        M::phaseA(K, rc, hx, rn, rs, An);
-        M::put_sy(&lds[j & 1][0][t], NT, An.sy);
-        const int x = j - 1;
-        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx);       // block-uniform
-        __syncthreads();
-        act_c = act_n;
-#pragma unroll
-        for (int f = 0; f < NF2; ++f) { rw[f] = rc[f]; rc[f] = re[f]; re[f] = re2[f]; rn[f] = rn2[f]; rs[f] = rs2[f]; }
-    };
-
-    // first row: nothing to emit yet.  Its x-products also stand in for the row before it, which
-    // is exactly the clamp-to-self rule when that row lies outside the domain, and is replaced
-    // before use otherwise.
-    row(j0, P0, P0, P0, true);
-    P2.sx = P0.sx;
-    int j = j0 + 1, last = 0;
-    for (;;) {
-        if (j > j1) { last = 0; break; }
-        row(j, P1, P0, P2, false); ++j;
-        if (j > j1) { last = 1; break; }
-        row(j, P2, P1, P0, false); ++j;
-        if (j > j1) { last = 2; break; }
-        row(j, P0, P2, P1, false); ++j;
-    }
-    // last owned row of the domain: its clamped East neighbour is the cell itself
-    if (j1 < xe) {
-        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx);
-        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx);
-        else emit(xe - 1, P2, P2.sx, P1.sx);
-    }
-}
-
-// Register-lean form of the tiled sweep.  Differences from sweep2d_march:
-//   * a thread reads only its own column from memory (5 loads per row instead of 15); the North /
-//     South neighbours' stored values of the row cross lanes through a second double-buffered LDS
-//     tile.  The two halo lanes have no neighbour on their outer side and use their own value
-//     there: what they publish for their inner neighbour (centre products and East/West face
-//     products) does not depend on their y-slopes, and they store nothing themselves;
-//   * the three live rows of stored values rotate through three register sets together with the
-//     phase-A results (the loop is unrolled by three): the x half-slopes are taken first, which
-//     retires the West row, and the load of row j+2 is issued straight into its registers.
+// Tiled sweep, shared-product arrangement ("march"): a block owns WCOLS adjacent columns (lanes run
+// along y, the contiguous index) plus one halo column on each side, and walks a chunk of x-planes.
+//   * a thread reads only its own column from memory; stored values and phase-A results of rows
+//     x-1, x, x+1 rotate through three register sets (the loop is unrolled by three, so nothing is
+//     moved): the East/West neighbour products never leave the thread.  The x half-slopes are taken
+//     first, which retires the West row, and the load of row j+2 is issued straight into its
+//     registers;
+//   * the North/South neighbours' stored values and products of the current row cross lanes through
+//     double-buffered LDS tiles, one barrier per row.  The two halo lanes have no neighbour on their
+//     outer side and use their own value there: what they publish for their inner neighbour (centre
+//     products and East/West face products) does not depend on their y-slopes, and they store nothing;
+//   * phase A is evaluated exactly once per cell (plus the two halo columns and two extra rows per
+//     chunk), and every cell is read from HBM once;
 //   * FILTER: the sweep that ends a step also applies the time filter (correctPrevTime) to the
 //     values it has just computed: prev <- pp + 0.5*(new - pp), so the new slot is not read back.
+//   iteration j:  x half-slopes of row j; issue the loads of row j+2 and of the mask of row j
+//                 phase A of row j  ->  publish its y-products in lds[j&1]
+//                 phase B of row j-1 (centre = row j-1, East = row j, West = row j-2,
+//                                     North/South = lds[(j-1)&1] of the neighbouring lanes)
+//                 one barrier
 template <class M, int NT, int MINW, bool FILTER, int WCOLS = NT - 2>
 __global__ void __launch_bounds__(NT, MINW)
 sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
@@ -1188,12 +1089,6 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                                   fprev);                                                          \
         fused = fpp != nullptr;                                                                    \
     } while (0)
-#define LAUNCH_MARCH(M, KK, NT, MINW, PF)                                                          \
-    do {                                                                                           \
-        dim3 block(NT), grid((p.ny + NT - 3) / (NT - 2), (x1 - x0 + ch - 1) / ch);                    \
-        hipExtLaunchKernelGGL((sweep2d_march<M, NT, MINW, PF>), grid, block, 0, h->stream, ea, eb, \
-                              0, KK, src, dst, act, x0, x1, p.ny, xlo, xhi, ch);                     \
-    } while (0)
         static const int swz = getenv("CFD_SWIZZLE") ? atoi(getenv("CFD_SWIZZLE")) : 1;     // XCD-contiguous tile order (tuning knob)
 #define LAUNCH_STREAM(NT, MINW, WC) LAUNCH_STREAM_RD(NT, MINW, WC, 3)
 #define LAUNCH_STREAM_RD(NT, MINW, WC, RDV)                                                         \
@@ -1209,55 +1104,30 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                                   xhi, ch, fpp, fprev, swz);                                       \
         fused = fpp != nullptr;                                                                    \
     } while (0)
+        // CFD_VARIANT (tuning / cross-checks): streamed messages 20..31, shared products 8..16
         if (fast) {
             switch (h->variant < 0 ? 30 : h->variant) {
                 case 20: LAUNCH_STREAM(128, 3, 126); break;
                 case 21: LAUNCH_STREAM(128, 2, 126); break;
                 case 22: LAUNCH_STREAM(64, 3, 62); break;
                 case 23: LAUNCH_STREAM(256, 3, 254); break;
-                case 24: LAUNCH_STREAM(256, 3, 240); break;     // tiles aligned to 128-byte lines
-                case 25: LAUNCH_STREAM_RD(128, 2, 126, 4); break;
-                case 26: LAUNCH_STREAM_RD(128, 2, 126, 5); break;
-                case 27: LAUNCH_STREAM_RD(256, 2, 240, 4); break;
+                case 24: LAUNCH_STREAM(256, 3, 240); break;
                 case 28: LAUNCH_STREAM_RD(256, 2, 240, 5); break;
-                case 29: LAUNCH_STREAM_RD(128, 2, 112, 5); break;
-                case 30: LAUNCH_STREAM(256, 2, 240); break;
                 case 31: LAUNCH_STREAM(128, 2, 112); break;
-                case 32: LAUNCH_STREAM(192, 2, 176); break;
-                case 33: LAUNCH_STREAM(512, 2, 496); break;
-                case 34: LAUNCH_STREAM(192, 3, 176); break;
-                case 1: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, true); break;
-                case 2: LAUNCH_MARCH(MathFast2, h->KF, 256, 2, false); break;
-                case 3: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, true); break;
-                case 4: LAUNCH_MARCH(MathFast2, h->KF, 128, 2, false); break;
-                case 5: LAUNCH_MARCH(MathFast2, h->KF, 64, 2, true); break;
-                case 6: LAUNCH_MARCH(MathFast2, h->KF, 128, 3, true); break;
-                case 7: LAUNCH_MARCH(MathFast2, h->KF, 256, 3, false); break;
                 case 8: LAUNCH_MARCH2(MathFast2, h->KF, 128, 2); break;
-                case 9: LAUNCH_MARCH2(MathFast2, h->KF, 128, 3); break;
-                case 10: LAUNCH_MARCH2(MathFast2, h->KF, 256, 3); break;
-                case 11: LAUNCH_MARCH2(MathFast2, h->KF, 64, 3); break;
                 case 12: LAUNCH_MARCH2(MathFast2, h->KF, 256, 2); break;
-                default: LAUNCH_MARCH(MathFast2, h->KF, 256, 1, true); break;
+                case 13: LAUNCH_MARCH2W(MathFast2, h->KF, 256, 2, 240); break;
+                default: LAUNCH_STREAM(256, 2, 240); break;     // 30: whole 128-byte lines per wave
             }
         } else {
             switch (h->variant < 0 ? 8 : h->variant) {
-                case 1: LAUNCH_MARCH(MathStrict2, h->K, 256, 2, true); break;
-                case 3: LAUNCH_MARCH(MathStrict2, h->K, 128, 1, true); break;
-                case 4: LAUNCH_MARCH(MathStrict2, h->K, 128, 1, false); break;
-                case 0: LAUNCH_MARCH(MathStrict2, h->K, 256, 1, true); break;
-                case 8: LAUNCH_MARCH2(MathStrict2, h->K, 128, 1); break;
                 case 9: LAUNCH_MARCH2(MathStrict2, h->K, 128, 2); break;
-                case 10: LAUNCH_MARCH2(MathStrict2, h->K, 256, 2); break;
                 case 12: LAUNCH_MARCH2(MathStrict2, h->K, 256, 1); break;
                 case 13: LAUNCH_MARCH2W(MathStrict2, h->K, 256, 1, 240); break;
                 case 14: LAUNCH_MARCH2W(MathStrict2, h->K, 128, 1, 112); break;
-                case 15: LAUNCH_MARCH2W(MathStrict2, h->K, 256, 2, 240); break;
-                case 16: LAUNCH_MARCH2W(MathStrict2, h->K, 192, 1, 176); break;
-                default: LAUNCH_MARCH(MathStrict2, h->K, 256, 2, false); break;
+                default: LAUNCH_MARCH2(MathStrict2, h->K, 128, 1); break;      // 8
             }
         }
-#undef LAUNCH_MARCH
 #undef LAUNCH_MARCH2
 #undef LAUNCH_MARCH2W
 #undef LAUNCH_STREAM
@@ -1677,9 +1547,8 @@ const char* cfd_kernel_name(cfd_handle* h) {
     }
     if (h->p.flags & CFD_FLAG_SIMPLE_KERNEL) return fast ? "sweep2d_simple<fast>" : "sweep2d_simple<strict>";
     const int v = h->variant < 0 ? (fast ? 30 : 8) : h->variant;
-    if (fast && v >= 20 && v <= 34) return "sweep2d_stream<fast>";
-    if (v >= 8) return fast ? "sweep2d_march2<fast>" : "sweep2d_march2<strict>";
-    return fast ? "sweep2d_march<fast>" : "sweep2d_march<strict>";
+    if (fast && !(v == 8 || v == 12 || v == 13)) return "sweep2d_stream<fast>";
+    return fast ? "sweep2d_march2<fast>" : "sweep2d_march2<strict>";
 }
 
 int cfd_sync(cfd_handle* h) {

@@ -40,7 +40,7 @@ def _assert_slots_bit_equal(g, b, what):
                                                 ((2, 200), 7, True), ((70, 300), 8, False),
                                                 ((37, 254), 9, False), ((33, 255), 10, False),
                                                 ((9, 509), 11, False)])
-@pytest.mark.parametrize("flags,chunk,variant", [(1, 32, 3), (0, 32, 3), (0, 1, 3), (0, 5, 3), (0, 32, 8), (0, 1, 8),
+@pytest.mark.parametrize("flags,chunk,variant", [(1, 32, 8), (0, 32, 12), (0, 1, 13), (0, 5, 14), (0, 32, 8), (0, 1, 8),
                                                  (0, 4, 12), (0, 7, 0)])
 def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags, chunk, variant, monkeypatch):
     monkeypatch.setenv("CFD_CHUNK", str(chunk))
