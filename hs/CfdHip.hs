@@ -6,7 +6,7 @@
 -- (SolutionDomain.AdjGraph / AdjNode / Grids) and include/cfd_hip.h.
 --
 -- Use: in Main.hs replace the body of runTimeSteps_Print's fold with CfdHip.runTimeStepsHip
--- (see INTEGRATION.md).  The solve loop, the printing and initialGrid_adj stay in Haskell.
+-- (the replacement is a one-line change of main).  The solve loop, the printing and initialGrid_adj stay in Haskell.
 module CfdHip
     ( HipGraph, withHipGraph, hipRunSingleStep, hipTotalDensity, hipTime, hipReadSlot, runTimeStepsHip
     ) where
