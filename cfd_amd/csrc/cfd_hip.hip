@@ -48,7 +48,7 @@ static int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------
 struct EventPair {
     hipEvent_t a, b;
-    int kind;       // 0 = sweep, 1 = sweep fused with the time filter
+    int kind;       // 0 = sweep, 1 = sweep fused with the time filter, 2 = two sweeps (+ filter) in one pass
 };
 
 struct cfd_handle {
@@ -72,6 +72,8 @@ struct cfd_handle {
     int chunk;              // x-planes per block of the tiled sweep
     int variant;            // tiled-kernel launch shape (tuning knob)
     bool march3_ok;         // a 3-D x-plane fits 32-bit byte offsets (tiled 3-D kernel usable)
+    bool pair_enabled;      // cfd_step runs its second and third sweep in one pass (env CFD_PAIR, default on)
+    int pair_chunk;         // x-planes per block of that kernel (env CFD_PAIR_CHUNK)
     // a sweep split into cfd_sweep_begin / cfd_sweep_end
     struct {
         bool open, step_time, with_filter, fused;
@@ -84,8 +86,8 @@ struct cfd_handle {
     // sweep timing
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
-    double t_ms[2];
-    int64_t t_launches[2];
+    double t_ms[3];
+    int64_t t_launches[3];
 };
 
 // field order inside a plane
@@ -665,6 +667,178 @@ sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     }
 }
 
+// Two sweeps in one pass over memory (re-associated arithmetic, streamed messages): dst = S(S(src)),
+// the second and third sweep of a step, optionally followed by the time filter.  The intermediate
+// field lives only in registers and LDS, so a step moves 81 + 161 bytes per cell instead of 323.
+// Pipeline per iteration j (one x-row per stage):
+//   stage 1:  phase A of row j on the stored values  ->  v1(j-1), the once-swept values of row j-1
+//   stage 2:  phase A of row j-2 on v1               ->  the twice-swept values of row j-3 (stored)
+// Lanes: WCOLS own columns first, then the two columns above / below the tile (once-swept values are
+// needed there), then the next two (they only feed stage 1's messages); the rest idle.
+// Clamp-to-self at the ends of the domain applies to each sweep separately: stage 1 gets it through
+// clamped row indices (a duplicated row publishes the messages of the row it duplicates); stage 2
+// needs copies of v1 itself: v1(r) for r below xlo1 / above xhi1 is a copy of v1(xlo1) / v1(xhi1), and
+// the first row of stage 2 takes its own West message.
+//   xlo, xhi:   lowest / highest x-plane that holds stored values (ghost planes included)
+//   xlo1, xhi1: lowest / highest x-plane on which once-swept values are defined
+// LDS single-buffered (stored values + messages of both stages, 22 doubles per thread), two barriers
+// per iteration: everything read was written in the previous iteration.
+template <int NT, int MINW, int WCOLS, bool FILTER>
+__global__ void __launch_bounds__(NT, MINW)
+sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ dst,
+             const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int xlo1, int xhi1,
+             int ch, const double* __restrict__ fpp, double* __restrict__ fprev) {
+    static_assert(WCOLS + 4 <= NT, "block too small for the tile and its two halo columns per side");
+    __shared__ double lraw1[NF2][NT], lmsg1[6][NT], lraw2[NF2][NT], lmsg2[6][NT];
+    const int t = threadIdx.x;
+    const unsigned wg = xcd_contiguous_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int bx = (int)(wg % gridDim.x), by = (int)(wg / gridDim.x);
+    const int ytile = bx * WCOLS;
+    // lanes: own columns, then +1 above, -1 below, +2 above, -2 below
+    const int y = t < WCOLS ? ytile + t
+                            : (t == WCOLS ? ytile + WCOLS
+                                          : (t == WCOLS + 1 ? ytile - 1 : (t == WCOLS + 2 ? ytile + WCOLS + 1 : ytile - 2)));
+    const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
+    const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
+    auto lane_of = [=](int c) {         // lane that holds column c; outside the tile and its halo: this lane
+        const int r = c - ytile;
+        if (r >= 0 && r < WCOLS) return r;
+        if (r == WCOLS) return WCOLS;
+        if (r == -1) return WCOLS + 1;
+        if (r == WCOLS + 1) return WCOLS + 2;
+        if (r == -2) return WCOLS + 3;
+        return t;
+    };
+    const int lnc = lane_of(yn), lsc = lane_of(ys);
+    const bool writer = t < WCOLS && y < ny;
+    const int xs = x0 + by * ch;
+    const int xe = xs + ch < nx ? xs + ch : nx;
+    const long plane5 = (long)NF2 * ny;
+    const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
+    const unsigned vc = t <= WCOLS + 3 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // idle lanes load nothing
+    const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;
+    auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
+    auto load_row = [&](int x, double v[NF2]) {
+        const PlaneRef p(src + (long)x * plane5, pbytes);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) v[f] = p.ld(vc, (unsigned)f * fstride);
+    };
+    auto load_act = [&](int x) { return PlaneRef(active + (long)x * ny, (unsigned)ny).ldb((unsigned)cy); };
+
+    double R[3][NF2];                       // stored values: rows j-1, j, j+1
+    double V[3][NF2];                       // once-swept values: rows j-3, j-2, j-1
+    double q1[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, rho1 = 1.0, mw1[3] = {0, 0, 0}, mw1D = 0.0;   // stage 1 pending row j-1
+    double q2[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0}, rho2 = 1.0, mw2[3] = {0, 0, 0}, mw2D = 0.0;   // stage 2 pending row j-3
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) V[u][f] = 1.0;
+    const int a2first = xs - 1 > xlo1 ? xs - 1 : xlo1;      // first row whose stage-2 phase A is used
+
+    auto iter = [&](int j, double* Rw, const double* Rc, const double* Re, double* Vw, double* Vc, double* Ve) {
+        // ---- stage 1: phase A of row j, then finish row j-1
+        double hx[NF2];
+        x_half_slopes2(Rc, Re, Rw, hx);
+        load_row(clampx(j + 2), Rw);                        // Rw is dead: row j+2 goes into it
+        const unsigned char act1 = load_act(clampx(j)), act2 = load_act(clampx(j - 2));
+        double pp[NF2];
+        const int xo = j - 3;                                // the row stage 2 finishes in this iteration
+        if (FILTER) {
+            const PlaneRef q(fpp + (long)(xo < xs ? xs : xo) * plane5, pbytes);
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
+        }
+        double rn[NF2], rs[NF2];
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { rn[f] = lraw1[f][lnc]; rs[f] = lraw1[f][lsc]; }
+        StreamA2 A;
+        phaseA2s(K, Rc, hx, rn, rs, mask_of(act1 != 0), A);
+        stream_west(A.q, A.coef, mw1, mw1D);
+        double vnew[NF2];                                    // v1(j-1)
+        vnew[F2_U] = stream_finish(q1[S2_U], c1[S2_U], A.me[S2_U], lmsg1[0][lnc], lmsg1[4][lsc]);
+        vnew[F2_V] = stream_finish(q1[S2_V], c1[S2_V], A.me[S2_V], lmsg1[1][lnc], lmsg1[5][lsc]);
+        vnew[F2_T] = stream_finish(q1[S2_T], c1[S2_T], A.me[S2_T], lmsg1[2][lnc], lmsg1[2][lsc]);
+        vnew[F2_DYE] = stream_finish(q1[S2_DYE], c1[S2_DYE], A.me[S2_DYE], lmsg1[3][lnc], lmsg1[3][lsc]);
+        vnew[F2_RHO] = rho1;
+        const int r1 = j - 1;
+        if (r1 > xhi1) {                                     // above the domain: a copy of the last defined row
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) vnew[f] = Vc[f];
+        }
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) Ve[f] = vnew[f];
+        if (r1 == xlo1) {                                    // below the domain: copies of the first defined row
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) { Vc[f] = vnew[f]; Vw[f] = vnew[f]; }
+        }
+        // ---- stage 2: phase A of row j-2 on the once-swept values, then finish row j-3
+        double hx2[NF2], rn2[NF2], rs2[NF2];
+        x_half_slopes2(Vc, Ve, Vw, hx2);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { rn2[f] = lraw2[f][lnc]; rs2[f] = lraw2[f][lsc]; }
+        StreamA2 B;
+        phaseA2s(K, Vc, hx2, rn2, rs2, mask_of(act2 != 0), B);
+        if (j - 2 == a2first) {     // clamp-to-self on the West side of the second sweep
+            mw2[0] = B.mw[0]; mw2[1] = B.mw[1]; mw2[2] = B.mw[2]; mw2D = B.me[S2_DYE];
+        }
+        stream_west(B.q, B.coef, mw2, mw2D);
+        {
+            const unsigned vs = (xo >= xs && xo < xe) ? vst : 0xFFFFFFF0u;
+            const double nU = stream_finish(q2[S2_U], c2[S2_U], B.me[S2_U], lmsg2[0][lnc], lmsg2[4][lsc]);
+            const double nV = stream_finish(q2[S2_V], c2[S2_V], B.me[S2_V], lmsg2[1][lnc], lmsg2[5][lsc]);
+            const double nT = stream_finish(q2[S2_T], c2[S2_T], B.me[S2_T], lmsg2[2][lnc], lmsg2[2][lsc]);
+            const double nD = stream_finish(q2[S2_DYE], c2[S2_DYE], B.me[S2_DYE], lmsg2[3][lnc], lmsg2[3][lsc]);
+            const int xr = xo < xs ? xs : (xo > xe - 1 ? xe - 1 : xo);
+            const PlaneRef d(dst + (long)xr * plane5, pbytes);
+            d.st_nt(vs, (unsigned)F2_RHO * fstride, rho2);
+            d.st_nt(vs, (unsigned)F2_T * fstride, nT);
+            d.st_nt(vs, (unsigned)F2_U * fstride, nU);
+            d.st_nt(vs, (unsigned)F2_V * fstride, nV);
+            d.st_nt(vs, (unsigned)F2_DYE * fstride, nD);
+            if (FILTER) {
+                const PlaneRef pv(fprev + (long)xr * plane5, pbytes);
+                const unsigned vm = c2[S2_U] != 0.0 ? vs : 0xFFFFFFF0u;
+                pv.st_nt(vs, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (rho2 - pp[F2_RHO])));
+                pv.st_nt(vs, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (nT - pp[F2_T])));
+                pv.st_nt(vm, (unsigned)F2_U * fstride, pp[F2_U] + (0.5 * (nU - pp[F2_U])));
+                pv.st_nt(vm, (unsigned)F2_V * fstride, pp[F2_V] + (0.5 * (nV - pp[F2_V])));
+                pv.st_nt(vm, (unsigned)F2_DYE * fstride, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])));
+            }
+        }
+        __syncthreads();            // every read of the previous iteration's tiles is done
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { lraw1[f][t] = Re[f]; lraw2[f][t] = vnew[f]; }
+        lmsg1[0][t] = A.ms[S2_U]; lmsg1[1][t] = A.ms[S2_V]; lmsg1[2][t] = A.ms[S2_T]; lmsg1[3][t] = A.ms[S2_DYE];
+        lmsg1[4][t] = A.mn[S2_U]; lmsg1[5][t] = A.mn[S2_V];
+        lmsg2[0][t] = B.ms[S2_U]; lmsg2[1][t] = B.ms[S2_V]; lmsg2[2][t] = B.ms[S2_T]; lmsg2[3][t] = B.ms[S2_DYE];
+        lmsg2[4][t] = B.mn[S2_U]; lmsg2[5][t] = B.mn[S2_V];
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { q1[f] = A.q[f]; c1[f] = A.coef[f]; q2[f] = B.q[f]; c2[f] = B.coef[f]; }
+        rho1 = A.rho; rho2 = B.rho;
+        mw1[0] = A.mw[0]; mw1[1] = A.mw[1]; mw1[2] = A.mw[2]; mw1D = A.me[S2_DYE];
+        mw2[0] = B.mw[0]; mw2[1] = B.mw[1]; mw2[2] = B.mw[2]; mw2D = B.me[S2_DYE];
+    };
+
+    const int jb = xs - 2, je = xe + 2;     // stage-1 rows; their indices are clamped where they are used
+#pragma unroll
+    for (int u = 0; u < 3; ++u) load_row(clampx(jb - 1 + u), R[u]);
+#pragma unroll
+    for (int f = 0; f < NF2; ++f) { lraw1[f][t] = R[1][f]; lraw2[f][t] = 1.0; }
+    for (int e = 0; e < 6; ++e) { lmsg1[e][t] = 0.0; lmsg2[e][t] = 0.0; }
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): only the previous iteration's operations are pending in the loop
+    int j = jb;
+    while (j <= je) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            iter(j, R[u % 3], R[(u + 1) % 3], R[(u + 2) % 3], V[u % 3], V[(u + 1) % 3], V[(u + 2) % 3]);
+            ++j;
+            if (j > je) break;
+        }
+    }
+}
+
 // A struct of doubles to / from a strided LDS column.
 template <class S>
 __device__ __forceinline__ void lds_put(double* __restrict__ l, int st, const S& s) {
@@ -1205,6 +1379,41 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
     return CFD_OK;
 }
 
+// Two in-place sweeps (+ filter) in one pass; only where pair_ok(h).
+static bool pair_ok(const cfd_handle* h) {
+    const cfd_params& p = h->p;
+    return h->two_d && (p.flags & CFD_FLAG_FAST_MATH) && !(p.flags & CFD_FLAG_SIMPLE_KERNEL) && !p.ghost_lo &&
+           !p.ghost_hi && h->pair_enabled && h->variant < 0;      // only beside the default launch shape
+}
+
+static int launch_pair(cfd_handle* h, const double* src, double* dst, const double* fpp, double* fprev) {
+    const cfd_params& p = h->p;
+    EventPair ev{};
+    if (h->timing) {
+        if (h->ev_free.empty()) {
+            HIP_TRY(hipEventCreate(&ev.a));
+            HIP_TRY(hipEventCreate(&ev.b));
+        } else {
+            ev = h->ev_free.back();
+            h->ev_free.pop_back();
+        }
+    }
+    hipEvent_t ea = h->timing ? ev.a : nullptr, eb = h->timing ? ev.b : nullptr;
+    const uint8_t* act = h->d_active + h->plane;
+    const int ch = h->pair_chunk;
+    constexpr int NT = 256, WC = 240;
+    dim3 block(NT), grid((p.ny + WC - 1) / WC, (p.nx + ch - 1) / ch);
+    if (fpp)
+        hipExtLaunchKernelGGL((sweep2d_pair<NT, 2, WC, true>), grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst, act,
+                              0, p.nx, p.ny, 0, p.nx - 1, 0, p.nx - 1, ch, fpp, fprev);
+    else
+        hipExtLaunchKernelGGL((sweep2d_pair<NT, 2, WC, false>), grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst, act,
+                              0, p.nx, p.ny, 0, p.nx - 1, 0, p.nx - 1, ch, fpp, fprev);
+    HIP_TRY(hipGetLastError());
+    if (h->timing) { ev.kind = 2; h->ev_used.push_back(ev); }
+    return CFD_OK;
+}
+
 extern "C" {
 
 const char* cfd_last_error(void) { return g_err.c_str(); }
@@ -1283,6 +1492,9 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->K = make_consts(p->dx, p->dy, p->dz, p->dt, p->lambda, p->suth, p->R, p->cv, p->k, p->dye_f);
     h->KF = make_fast_consts(h->K, p->dx, p->dy, p->dz);
     h->march3_ok = (double)NF3 * (double)h->plane * 8.0 < 4.0e9;
+    h->pair_enabled = getenv("CFD_PAIR") ? atoi(getenv("CFD_PAIR")) != 0 : true;
+    h->pair_chunk = getenv("CFD_PAIR_CHUNK") ? atoi(getenv("CFD_PAIR_CHUNK")) : 32;
+    if (h->pair_chunk < 1) h->pair_chunk = 1;
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
     if (const char* e = getenv("CFD_CHUNK")) { int v = atoi(e); if (v >= 1) h->chunk = v; }
@@ -1290,7 +1502,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
     h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;
-    h->timing = false; h->t_ms[0] = h->t_ms[1] = 0.0; h->t_launches[0] = h->t_launches[1] = 0;
+    h->timing = false; h->t_ms[0] = h->t_ms[1] = h->t_ms[2] = 0.0; h->t_launches[0] = h->t_launches[1] = h->t_launches[2] = 0;
     h->mew.assign(fields[5], fields[5] + n);
 
 #define CREATE_TRY(expr)                                                                       \
@@ -1392,6 +1604,29 @@ int cfd_sweep_and_filter(cfd_handle* h) {
     return fused ? CFD_OK : cfd_time_filter(h);
 }
 
+int cfd_sweep_pair_and_filter(cfd_handle* h) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sweep_pair_and_filter: null handle");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_pair_and_filter: a split sweep is open (call cfd_sweep_end first)");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!pair_ok(h)) {
+        int rc = cfd_sweep(h, 0);
+        return rc ? rc : cfd_sweep_and_filter(h);
+    }
+    const double* fpp = nullptr;
+    double* fprev = nullptr;
+    if (h->cat > 1) {
+        const int tb = (h->cmt + 2) % 3, tc = (tb + 2) % 3;
+        fpp = slot_base(h, tc);
+        fprev = slot_base(h, tb);
+    }
+    int rc = launch_pair(h, slot_base(h, h->cmt), slot_base(h, 3), fpp, fprev);
+    if (rc) return rc;
+    const int t = h->map[h->cmt];
+    h->map[h->cmt] = h->map[3];
+    h->map[3] = t;
+    return CFD_OK;
+}
+
 int cfd_sweep_begin(cfd_handle* h, int step_time, int with_filter) {
     if (!h) return fail(CFD_E_ARG, "cfd_sweep_begin: null handle");
     if (h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_begin: a split sweep is already open");
@@ -1453,8 +1688,7 @@ int cfd_step(cfd_handle* h, int nsteps) {
         // the third sweep's kernel where that kernel supports it, as its own launch otherwise.
         int rc;
         if ((rc = cfd_sweep(h, 1))) return rc;
-        if ((rc = cfd_sweep(h, 0))) return rc;
-        if ((rc = cfd_sweep_and_filter(h))) return rc;
+        if ((rc = cfd_sweep_pair_and_filter(h))) return rc;
     }
     return CFD_OK;
 }
@@ -1580,7 +1814,7 @@ static int collect_timing(cfd_handle* h) {
 
 int cfd_kernel_timing(cfd_handle* h, int kind, double* total_ms, int64_t* launches, int reset) {
     if (!h) return fail(CFD_E_ARG, "cfd_kernel_timing: null handle");
-    if (kind < 0 || kind > 1) return fail(CFD_E_ARG, "cfd_kernel_timing: kind must be 0 or 1");
+    if (kind < 0 || kind > 2) return fail(CFD_E_ARG, "cfd_kernel_timing: kind must be 0, 1 or 2");
     int rc = collect_timing(h);
     if (rc) return rc;
     if (total_ms) *total_ms = h->t_ms[kind];

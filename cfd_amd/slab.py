@@ -174,6 +174,9 @@ class SlabGraph:
         return self
 
     def step(self, nsteps=1):
+        if self.world == 1 and hasattr(self.backend, "step"):
+            self.backend.step(nsteps)       # undecomposed: the library's own step (second and third sweep in one pass)
+            return self
         for _ in range(nsteps):
             self._sweep(True, False)
             self._sweep(False, False)

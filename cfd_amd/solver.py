@@ -109,6 +109,12 @@ class AdjGraph:
         check(self._lib.cfd_sweep_and_filter(self._h))
         return self
 
+    def sweep_pair_and_filter(self):
+        """The second and third sweep of a step and the time filter (one pass over memory where the
+        library supports it)."""
+        check(self._lib.cfd_sweep_pair_and_filter(self._h))
+        return self
+
     def sweep_begin(self, step_time, with_filter=False):
         """First half of a split sweep: the planes that need no ghost plane (see include/cfd_hip.h)."""
         check(self._lib.cfd_sweep_begin(self._h, 1 if step_time else 0, 1 if with_filter else 0))
@@ -138,7 +144,8 @@ class AdjGraph:
         return ms.value, n.value
 
     def kernel_timing(self, kind, reset=True):
-        """(total milliseconds, launches) of kind 0 = plain sweeps, 1 = sweeps fused with the time filter."""
+        """(total milliseconds, launches) of kind 0 = plain sweeps, 1 = sweeps fused with the time filter,
+        2 = two sweeps and the filter in one pass."""
         ms, n = ctypes.c_double(), ctypes.c_int64()
         check(self._lib.cfd_kernel_timing(self._h, int(kind), ctypes.byref(ms), ctypes.byref(n), int(bool(reset))))
         return ms.value, n.value

@@ -118,6 +118,12 @@ int cfd_time_filter(cfd_handle *h);
  * src/Main.hs:194-197 with next == 2), in one kernel where the sweep kernel supports it. */
 int cfd_sweep_and_filter(cfd_handle *h);
 
+/* The tail of runSingleStep (src/Main.hs:194-197 with next == 1 and next == 2): two sweeps that do not
+ * advance time, then correctPrevTime.  For 2-D grids with CFD_FLAG_FAST_MATH and no ghost planes the two
+ * sweeps run in one pass over memory (the intermediate field never reaches HBM); otherwise this is
+ * cfd_sweep(h, 0) followed by cfd_sweep_and_filter(h).  Results are identical either way. */
+int cfd_sweep_pair_and_filter(cfd_handle *h);
+
 /* The same sweep (applyDiffEq_adj, src/Main.hs:202-226) in two halves, for a slab that exchanges
  * ghost planes with its neighbours: cfd_sweep_begin launches every owned plane whose stencil reads
  * owned planes only (all but the first / last plane where a ghost plane exists), so that the
@@ -179,7 +185,8 @@ int cfd_set_timing(cfd_handle *h, int enable);
 int cfd_sweep_timing(cfd_handle *h, double *total_ms, int64_t *launches, int reset);
 
 /* As cfd_sweep_timing, per kernel kind: 0 = plain sweep launches, 1 = sweeps fused with the time
- * filter (the last sweep of a cfd_step once currAbsTime > 1). */
+ * filter (the last sweep of a step once currAbsTime > 1), 2 = launches that do the second and third
+ * sweep of a step and the filter in one pass (cfd_sweep_pair_and_filter where it applies). */
 int cfd_kernel_timing(cfd_handle *h, int kind, double *total_ms, int64_t *launches, int reset);
 
 /* Number of live fields the device holds per slot: 5 when nz == 1 and W is identically
