@@ -1404,11 +1404,11 @@ static int launch_pair(cfd_handle* h, const double* src, double* dst, const doub
     constexpr int NT = 256, WC = 240;
     dim3 block(NT), grid((p.ny + WC - 1) / WC, (p.nx + ch - 1) / ch);
     if (fpp)
-        hipExtLaunchKernelGGL((sweep2d_pair<NT, 2, WC, true>), grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst, act,
-                              0, p.nx, p.ny, 0, p.nx - 1, 0, p.nx - 1, ch, fpp, fprev);
+        hipExtLaunchKernelGGL((sweep2d_pair<NT, 2, WC, true>), grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
+                              act, 0, p.nx, p.ny, 0, p.nx - 1, 0, p.nx - 1, ch, fpp, fprev);
     else
-        hipExtLaunchKernelGGL((sweep2d_pair<NT, 2, WC, false>), grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst, act,
-                              0, p.nx, p.ny, 0, p.nx - 1, 0, p.nx - 1, ch, fpp, fprev);
+        hipExtLaunchKernelGGL((sweep2d_pair<NT, 2, WC, false>), grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
+                              act, 0, p.nx, p.ny, 0, p.nx - 1, 0, p.nx - 1, ch, fpp, fprev);
     HIP_TRY(hipGetLastError());
     if (h->timing) { ev.kind = 2; h->ev_used.push_back(ev); }
     return CFD_OK;
@@ -1493,7 +1493,18 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->KF = make_fast_consts(h->K, p->dx, p->dy, p->dz);
     h->march3_ok = (double)NF3 * (double)h->plane * 8.0 < 4.0e9;
     h->pair_enabled = getenv("CFD_PAIR") ? atoi(getenv("CFD_PAIR")) != 0 : true;
-    h->pair_chunk = getenv("CFD_PAIR_CHUNK") ? atoi(getenv("CFD_PAIR_CHUNK")) : 32;
+    if (getenv("CFD_PAIR_CHUNK")) {
+        h->pair_chunk = atoi(getenv("CFD_PAIR_CHUNK"));
+    } else {
+        // The one-pass kernel computes five extra rows per chunk, so chunks should be long; two of its
+        // blocks fit a CU, and the whole grid running as one round of blocks was the fastest shape measured.
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
+        const int tiles = (p->ny + 239) / 240;
+        const int chunks = (2 * cus) / tiles > 0 ? (2 * cus) / tiles : 1;
+        h->pair_chunk = (p->nx + chunks - 1) / chunks;
+        if (h->pair_chunk < 32) h->pair_chunk = 32;
+    }
     if (h->pair_chunk < 1) h->pair_chunk = 1;
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;

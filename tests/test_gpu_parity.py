@@ -108,6 +108,7 @@ def test_two_sweeps_in_one_pass_equal_two_launches(shape, chunk, monkeypatch):
     first step (no filter yet) on; shapes with one row, one column, ragged tiles and several chunks,
     inactive cells included."""
     monkeypatch.setenv("CFD_PAIR_CHUNK", str(chunk))
+    monkeypatch.setenv("CFD_PAIR", "1")
     params, fields, active = small_case(shape[0], shape[1], 1, 23)
     ga = _gpu_graph(params, fields, active, 4)
     monkeypatch.setenv("CFD_PAIR", "0")
