@@ -12,5 +12,6 @@ g = AdjGraph(params, fields, active)
 for i in range(int(os.environ.get("NSWEEP", "6"))):
     g.sweep(i % 3 == 0)
 g.time_filter()
+g.step(int(os.environ.get("NSTEP", "3")))     # whole steps: the launch kinds the default path uses
 g.sync()
 print("done", g.kernel_name())
