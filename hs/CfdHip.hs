@@ -47,6 +47,7 @@ foreign import ccall safe "cfd_step" c_step :: Ptr CfdHandle -> CInt -> IO CInt
 foreign import ccall safe "cfd_sweep" c_sweep :: Ptr CfdHandle -> CInt -> IO CInt
 foreign import ccall safe "cfd_time_filter" c_filter :: Ptr CfdHandle -> IO CInt
 foreign import ccall safe "cfd_sweep_and_filter" c_sweepAndFilter :: Ptr CfdHandle -> IO CInt
+foreign import ccall safe "cfd_sweep_pair_and_filter" c_sweepPairAndFilter :: Ptr CfdHandle -> IO CInt
 foreign import ccall safe "cfd_sweep_begin" c_sweepBegin :: Ptr CfdHandle -> CInt -> CInt -> IO CInt
 foreign import ccall safe "cfd_sweep_end" c_sweepEnd :: Ptr CfdHandle -> IO CInt
 foreign import ccall safe "cfd_total_density" c_density :: Ptr CfdHandle -> Ptr Double -> IO CInt
