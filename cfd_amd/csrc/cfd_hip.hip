@@ -1166,6 +1166,76 @@ time_filter_kernel(const double* __restrict__ cur, const double* __restrict__ pp
     }
 }
 
+// Output property of the cells of one z-level of a time slot: `prop_adj Nondirectional prp c Prev`
+// as adjGraphToGrid evaluates it (src/Main.hs:339-346, src/SolutionDomain.hs:540-575).  prop is
+// the reference's Property enum (CFD_PROPERTY_*).  Stored properties are copied; Speed, Pressure
+// and Mew are cell-centre formulas; Vorticity differentiates at the East face: along x the centre
+// difference to the East neighbour, along y / z the difference of the East-face (limited) values
+// of the two neighbours in that direction (approximateDerivative_adj, :506-538).  The reference's
+// operation order throughout.  One thread per cell of the slice; out[x*ny + y].
+struct SliceFields {
+    const double* base;     // plane x = 0, field 0 of the slot
+    long plane;             // ny*nz
+    int nf, nz;
+    int iU, iV, iW, iRho, iT, iDye;     // field index inside a plane; iW < 0: W is identically +0
+    int xlo, xhi;           // lowest / highest readable x-plane (ghost planes included)
+    __device__ double at(int f, int x, int y, int z) const {
+        return base[((long)x * nf + f) * plane + (long)y * nz + z];
+    }
+    // value at the East face of cell (x, y, z): vc + 0.5 * superbee(up - vc, vc - lo)
+    __device__ double east(int f, int x, int y, int z) const {
+        const double vc = at(f, x, y, z);
+        const double up = at(f, x + 1 > xhi ? xhi : x + 1, y, z), lo = at(f, x - 1 < xlo ? xlo : x - 1, y, z);
+        return vc + half_slope(up, vc, lo);
+    }
+};
+
+__global__ void __launch_bounds__(256)
+property_slice_kernel(SweepConsts K, SliceFields F, int nx, int ny, int zl, int prop, double* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)nx * ny) return;
+    const int x = (int)(i / ny), y = (int)(i % ny), z = zl;
+    const int nz = F.nz;
+    double v;
+    switch (prop) {
+    case CFD_PROPERTY_SPEED: {
+        const double u = F.at(F.iU, x, y, z), w = F.at(F.iV, x, y, z), q = F.iW >= 0 ? F.at(F.iW, x, y, z) : 0.0;
+        v = sqrt(((0.0 + u * u) + w * w) + q * q);
+        break;
+    }
+    case CFD_PROPERTY_VORTICITY: {
+        const int xe = x + 1 > F.xhi ? F.xhi : x + 1;
+        const int yn = y + 1 < ny ? y + 1 : y, ys = y > 0 ? y - 1 : y;
+        const int zt = z + 1 < nz ? z + 1 : z, zb = z > 0 ? z - 1 : z;
+        // components for the pairs (U,V), (U,W), (V,W)
+        const double c1 = ((F.at(F.iV, xe, y, z) - F.at(F.iV, x, y, z)) * 1.0) / K.hx -
+                          ((F.east(F.iU, x, yn, z) - F.east(F.iU, x, ys, z)) * 1.0) / K.Hy;
+        double c2, c3;
+        if (F.iW >= 0) {
+            c2 = ((F.at(F.iW, xe, y, z) - F.at(F.iW, x, y, z)) * 1.0) / K.hx -
+                 ((F.east(F.iU, x, y, zt) - F.east(F.iU, x, y, zb)) * 1.0) / K.Hz;
+            c3 = ((F.east(F.iW, x, yn, z) - F.east(F.iW, x, ys, z)) * 1.0) / K.Hy -
+                 ((F.east(F.iV, x, y, zt) - F.east(F.iV, x, y, zb)) * 1.0) / K.Hz;
+        } else {
+            // one z-level and W == +0: every difference above is of identical values, 0/h - 0/h = 0
+            c2 = 0.0;
+            c3 = 0.0;
+        }
+        v = sqrt(((0.0 + c1 * c1) + c2 * c2) + c3 * c3);
+        break;
+    }
+    case CFD_PROPERTY_PRESSURE: v = (K.R * F.at(F.iT, x, y, z)) * F.at(F.iRho, x, y, z); break;
+    case CFD_PROPERTY_U: v = F.at(F.iU, x, y, z); break;
+    case CFD_PROPERTY_V: v = F.at(F.iV, x, y, z); break;
+    case CFD_PROPERTY_W: v = F.iW >= 0 ? F.at(F.iW, x, y, z) : 0.0; break;
+    case CFD_PROPERTY_DENSITY: v = F.at(F.iRho, x, y, z); break;
+    case CFD_PROPERTY_TEMPERATURE: v = F.at(F.iT, x, y, z); break;
+    case CFD_PROPERTY_MEW: v = mu_of(K, F.at(F.iT, x, y, z)); break;
+    default: v = F.at(F.iDye, x, y, z); break;
+    }
+    out[i] = v;
+}
+
 // Sum of one field over the owned planes.  Stage 1: fixed grid, grid-stride, wavefront shuffle,
 // then LDS across the block's waves; one partial per block.  Stage 2: one block folds the
 // partials.  Fixed launch geometry makes the result reproducible from run to run.
@@ -1740,6 +1810,35 @@ int cfd_read_fields(cfd_handle* h, int slot_rel, double* const out[CFD_NPROP]) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->two_d) std::memset(out[2], 0, n * sizeof(double));   // W is exactly +0 throughout
     std::memcpy(out[5], h->mew.data(), n * sizeof(double));
+    return CFD_OK;
+}
+
+int cfd_property_slice(cfd_handle* h, int property, int z_level, int slot_rel, double* out) {
+    if (!h || !out) return fail(CFD_E_ARG, "cfd_property_slice: null pointer");
+    if (property < CFD_PROPERTY_SPEED || property > CFD_PROPERTY_DYE)
+        return fail(CFD_E_ARG, "cfd_property_slice: property must be 0..9 (Speed .. Dye)");
+    if (z_level < 0 || z_level >= h->p.nz) return fail(CFD_E_ARG, "cfd_property_slice: z_level outside the grid");
+    if (slot_rel < 0 || slot_rel > 2) return fail(CFD_E_ARG, "cfd_property_slice: slot_rel must be 0, 1 or 2");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_property_slice: a split sweep is open (call cfd_sweep_end first)");
+    HIP_TRY(hipSetDevice(h->device));
+    const int t = ((h->cmt - slot_rel) % 3 + 3) % 3;
+    SliceFields F;
+    F.base = slot_base(h, t);
+    F.plane = (long)h->plane;
+    F.nf = h->nf;
+    F.nz = h->p.nz;
+    if (h->two_d) { F.iU = F2_U; F.iV = F2_V; F.iW = -1; F.iRho = F2_RHO; F.iT = F2_T; F.iDye = F2_DYE; }
+    else { F.iU = 0; F.iV = 1; F.iW = 2; F.iRho = 3; F.iT = 4; F.iDye = 5; }
+    F.xlo = h->p.ghost_lo ? -1 : 0;
+    F.xhi = h->p.ghost_hi ? h->p.nx : h->p.nx - 1;
+    // the scratch slot is free between sweeps and larger than a slice: it stages the result
+    double* stage = h->buf[h->map[3]];
+    const long n = (long)h->p.nx * h->p.ny;
+    hipLaunchKernelGGL(property_slice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->K, F,
+                       h->p.nx, h->p.ny, z_level, property, stage);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, stage, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return CFD_OK;
 }
 

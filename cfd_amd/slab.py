@@ -189,6 +189,14 @@ class SlabGraph:
     def read_fields(self, slot_rel=0):
         return self.backend.read_fields(slot_rel)
 
+    def property_slice(self, prp, z_level=None):
+        """This rank's rows of the output slice (adjGraphToGrid, src/Main.hs:339-346) of the current slot.
+        Vorticity reads the neighbouring slabs' boundary planes, so the ghost planes are exchanged first
+        (collective: every rank calls it)."""
+        if self.world != 1:
+            self.exchange()
+        return self.backend.property_slice(prp, z_level)
+
     def sync(self):
         self.backend.sync()
 

@@ -13,6 +13,7 @@ each function returns the graph it was given rather than a new one.
     correctPrevTime g calcSteps_adj          correctPrevTime(g)
     totalDensity g                           totalDensity(g)
     currModTime g / currAbsTime g            g.currModTime / g.currAbsTime
+    adjGraphToGrid g prp rowLength zLevel    adjGraphToGrid(g, prp, zLevel)
     runTimeSteps_Print                       runTimeSteps_Print(g, nsteps)
 """
 import ctypes
@@ -23,6 +24,8 @@ from . import _capi
 from ._capi import CfdParams, check
 
 PROPERTIES = ("U", "V", "W", "Density", "Temperature", "Mew", "Dye")   # propIndex order
+# data Property (src/SolutionDomain.hs:30), the numbering of output slices
+OUTPUT_PROPERTIES = ("Speed", "Vorticity", "Pressure", "U", "V", "W", "Density", "Temperature", "Mew", "Dye")
 
 # reference constants (src/SolutionDomain.hs:237-260, src/Main.hs:55-56, :148)
 TIME_STEP = 0.00001
@@ -89,6 +92,17 @@ class AdjGraph:
         """Seven host arrays of time slot currModTime - slot_rel (0, 1 or 2 slots back)."""
         out = [np.empty(self.n, dtype=np.float64) for _ in range(_capi.CFD_NPROP)]
         check(self._lib.cfd_read_fields(self._h, int(slot_rel), _capi.ptr_array(out)))
+        return out
+
+    def property_slice(self, prp, z_level=None, slot_rel=0):
+        """adjGraphToGrid (src/Main.hs:339-346): output property `prp` (name or index in OUTPUT_PROPERTIES)
+        of the cells with z == z_level as an (nx, ny) array; z_level defaults to the reference's
+        quot (maxPos Z) 2.  slot_rel = 0 is the slot the reference reads."""
+        k = OUTPUT_PROPERTIES.index(prp) if isinstance(prp, str) else int(prp)
+        if z_level is None:
+            z_level = (self._p.nz - 1) // 2
+        out = np.empty((self._p.nx, self._p.ny), dtype=np.float64)
+        check(self._lib.cfd_property_slice(self._h, k, int(z_level), int(slot_rel), out.ctypes.data))
         return out
 
     # --- update ----------------------------------------------------------------------------
@@ -200,6 +214,11 @@ def correctPrevTime(g):
 def totalDensity(g):
     """src/Main.hs:269-270."""
     return g.total_density()
+
+
+def adjGraphToGrid(g, prp, zLevel=None):
+    """src/Main.hs:339-346 (rowLength is always ny): list of nx rows of ny values."""
+    return g.property_slice(prp, zLevel).tolist()
 
 
 def _hs_show_double(v):

@@ -3,7 +3,10 @@
 // host binds it.  Plain C++ (no HIP on the host side); links only against include/cfd_hip.h's
 // entry points.
 //
-//   cfd_main [steps] [--fast] [--nx N --ny N]
+//   cfd_main [steps] [--fast] [--nx N --ny N] [--string-domain PROPERTY]
+//
+// --string-domain k also prints, after every step, the slice of Property k (0 Speed .. 9 Dye) the way the
+// reference's stringDomain does (src/Main.hs:349-352; the call is commented out at :302).
 //
 // Builds the shipped configuration (initialGrid_adj, src/SolutionDomain.hs:262-353, in closed form;
 // 301 x 151 x 1 unless --nx/--ny scale it) and prints the reference's five lines per step.
@@ -52,10 +55,12 @@ int main(int argc, char** argv) {
     long steps = 5;
     int nx = 301, ny = 151;
     uint32_t flags = 0;
+    int show_prop = -1;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--fast")) flags |= CFD_FLAG_FAST_MATH;
         else if (!std::strcmp(argv[i], "--nx") && i + 1 < argc) nx = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--ny") && i + 1 < argc) ny = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--string-domain") && i + 1 < argc) show_prop = std::atoi(argv[++i]);
         else steps = std::atol(argv[i]);
     }
     cfd_params p;
@@ -94,6 +99,18 @@ int main(int argc, char** argv) {
         if (cfd_total_density(h, &total) != CFD_OK) return die("cfd_total_density");
         std::printf("%zu\nstep: %ld\ntimeLevel: %d\ntimeLevelAbsolute: %d\ntotalDensity: %s\n \n", n, step, cmt, cat,
                     hs_show_double(total).c_str());
+        if (show_prop >= 0) {
+            // adjGraphToGrid next prp (1 + maxPos Y) (quot (maxPos Z) 2), one text row per x
+            std::vector<double> slice(n);
+            if (cfd_property_slice(h, show_prop, (p.nz - 1) / 2, 0, slice.data()) != CFD_OK)
+                return die("cfd_property_slice");
+            std::string text;
+            for (int x = 0; x < nx; ++x) {
+                text += "\n";
+                for (int y = 0; y < ny; ++y) text += " " + hs_show_double(slice[(size_t)x * ny + y]);
+            }
+            std::printf("%s\n", text.c_str());
+        }
     }
     cfd_destroy(h);
     return 0;

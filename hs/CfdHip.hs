@@ -48,6 +48,7 @@ foreign import ccall safe "cfd_sweep" c_sweep :: Ptr CfdHandle -> CInt -> IO CIn
 foreign import ccall safe "cfd_time_filter" c_filter :: Ptr CfdHandle -> IO CInt
 foreign import ccall safe "cfd_sweep_and_filter" c_sweepAndFilter :: Ptr CfdHandle -> IO CInt
 foreign import ccall safe "cfd_sweep_pair_and_filter" c_sweepPairAndFilter :: Ptr CfdHandle -> IO CInt
+foreign import ccall safe "cfd_property_slice" c_propertySlice :: Ptr CfdHandle -> CInt -> CInt -> CInt -> Ptr Double -> IO CInt
 foreign import ccall safe "cfd_sweep_begin" c_sweepBegin :: Ptr CfdHandle -> CInt -> CInt -> IO CInt
 foreign import ccall safe "cfd_sweep_end" c_sweepEnd :: Ptr CfdHandle -> IO CInt
 foreign import ccall safe "cfd_total_density" c_density :: Ptr CfdHandle -> Ptr Double -> IO CInt
@@ -112,6 +113,17 @@ hipReadSlot (HipGraph h) n slotRel = do
     withMany withForeignPtr bufs $ \ps -> withArray ps $ \pp ->
         c_read h (fromIntegral slotRel) pp >>= check "cfd_read_fields"
     return [SV.unsafeFromForeignPtr0 b n | b <- bufs]
+
+-- | adjGraphToGrid (Main.hs:339-346) on the device: nx rows of ny values of Property prp at z == zLevel.
+hipGraphToGrid :: HipGraph -> Property -> Int -> IO [[Double]]
+hipGraphToGrid (HipGraph h) prp zLevel = do
+    let nx = maxPos X + 1
+        ny = maxPos Y + 1
+    buf <- mallocForeignPtrArray (nx * ny)
+    withForeignPtr buf $ \p ->
+        c_propertySlice h (fromIntegral (fromEnum prp)) (fromIntegral zLevel) 0 p >>= check "cfd_property_slice"
+    let v = SV.unsafeFromForeignPtr0 buf (nx * ny)
+    return [SV.toList (SV.slice (x * ny) ny v) | x <- [0 .. nx - 1]]
 
 -- | The solve loop of Main.hs:278-306 with the update on the GPU; prints the same five lines.
 runTimeStepsHip :: AdjGraph -> Int -> IO ()

@@ -144,6 +144,24 @@ int cfd_total_density(cfd_handle *h, double *out);
  * (pushBackTime, src/SolutionDomain.hs:422-423).  out[i] receives nx*ny*nz doubles. */
 int cfd_read_fields(cfd_handle *h, int slot_rel, double *const out[CFD_NPROP]);
 
+/* Output properties, numbered as the reference's Property enum (src/SolutionDomain.hs:30). */
+enum {
+    CFD_PROPERTY_SPEED = 0, CFD_PROPERTY_VORTICITY = 1, CFD_PROPERTY_PRESSURE = 2, CFD_PROPERTY_U = 3,
+    CFD_PROPERTY_V = 4, CFD_PROPERTY_W = 5, CFD_PROPERTY_DENSITY = 6, CFD_PROPERTY_TEMPERATURE = 7,
+    CFD_PROPERTY_MEW = 8, CFD_PROPERTY_DYE = 9
+};
+
+/* adjGraphToGrid vs prp rowLength zLevel (src/Main.hs:339-346): `prop_adj Nondirectional prp c Prev`
+ * (src/SolutionDomain.hs:540-575) of every cell with z == z_level, computed on the device and
+ * copied to out[x*ny + y] (nx rows of ny values; the reference calls it with rowLength = ny and
+ * zLevel = (nz-1)/2, src/Main.hs:288).  Speed = |(U,V,W)|; Vorticity = magnitude of the three
+ * curl components taken at the East face; Pressure = (R T) rho; Mew from Sutherland's law (the
+ * stored Mew is not used); the other seven are the stored values.  The reference evaluates it on
+ * slot currModTime (side Prev resolves to the position's own slot): slot_rel = 0; 1 and 2 give the
+ * filtered history slots.  In a slab run Vorticity reads the ghost planes of that slot: exchange
+ * them first. */
+int cfd_property_slice(cfd_handle *h, int property, int z_level, int slot_rel, double *out);
+
 /* currModTime and currAbsTime of the AdjGraph (src/SolutionDomain.hs:53-57). */
 int cfd_time(cfd_handle *h, int *curr_mod_time, int *curr_abs_time);
 

@@ -52,6 +52,7 @@ def lib():
         L.ob_time.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.ob_slot_ptr.restype = ctypes.POINTER(ctypes.c_double)
         L.ob_slot_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.ob_property.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.ob_superbee.restype = ctypes.c_double
         L.ob_superbee.argtypes = [ctypes.c_double, ctypes.c_double]
         L.ob_mu.restype = ctypes.c_double
@@ -97,6 +98,18 @@ class OracleB:
         out = [np.empty(self.n, dtype=np.float64) for _ in range(7)]
         self.L.ob_read_fields(self.h, slot_rel, _ptr_array(out))
         return out
+
+    def property_field(self, prop, slot_rel=0):
+        """Output property (reference Property enum: 0 Speed 1 Vorticity 2 Pressure 3 U 4 V 5 W 6 Density
+        7 Temperature 8 Mew 9 Dye) of every cell of slot cmt-slot_rel, node order."""
+        out = np.empty(self.n, dtype=np.float64)
+        self.L.ob_property(self.h, int(prop), int(slot_rel), out.ctypes.data)
+        return out
+
+    def property_slice(self, prop, z_level, slot_rel=0):
+        """adjGraphToGrid (src/Main.hs:339-346): the z = z_level slice as an (nx, ny) array."""
+        p = self.p
+        return self.property_field(prop, slot_rel).reshape(p.nx, p.ny, p.nz)[:, :, z_level].copy()
 
     def slot_view(self, slot_rel, q):
         """Writable numpy view of live field q (U V W Density Temperature Dye) of slot cmt-slot_rel."""

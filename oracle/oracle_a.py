@@ -19,7 +19,7 @@ fold orders, same operand orders) so that a reader can diff it by eye:
   offsetPosition_adj, getNode, getNodeVal src/SolutionDomain.hs:450-468
   average                                 src/SolutionDomain.hs:475-479
   approximateDerivative_adj               src/SolutionDomain.hs:506-538
-  prop_adj                                src/SolutionDomain.hs:543-575
+  prop_adj (incl. Speed, Vorticity)       src/SolutionDomain.hs:540-575
   propLimitedSlope_adj                    src/SolutionDomain.hs:644-659
   propCentralDiff_adj                     src/SolutionDomain.hs:687-713
   sideArea_adj, sideLength_adj            src/SolutionDomain.hs:840-867
@@ -28,6 +28,7 @@ fold orders, same operand orders) so that a reader can diff it by eye:
   equations, calcSteps_adj                src/Main.hs:89-187
   applyDiffEq_adj, correctPrevTime,
   runSingleStep, totalDensity             src/Main.hs:189-270
+  makeRows, adjGraphToGrid                src/Main.hs:334-346
 
 Slow by design (closures rebuilt per cell, per equation, per sweep exactly as
 the reference does); meant for grids of a few hundred cells.
@@ -367,7 +368,7 @@ def propLimitedSlope_adj(prp, position, side, env):   # :644-659
     return valCenter - 0.5 * ave
 
 
-def prop_adj(schemeType, prp, pos, side, env):    # :543-575 (Speed/Vorticity branches not on the path)
+def prop_adj(schemeType, prp, pos, side, env):    # :543-575
     def scheme(p, ps, sd, e):
         if sd == CENTER or sd == NOW or sd == PREV:
             return propCentralDiff_adj(p, ps, sd, e)
@@ -377,9 +378,34 @@ def prop_adj(schemeType, prp, pos, side, env):    # :543-575 (Speed/Vorticity br
         return fdiv(sutherlandLambda * fpow(t, 1.5), t + sutherlandConstant)
     if prp == PRESSURE:
         return gasConstantR * scheme(TEMPERATURE, pos, side, env) * scheme(DENSITY, pos, side, env)
-    if prp in (SPEED, VORTICITY):
-        raise NotImplementedError("derived output fields are not on the update path")
+    momentums = [U, V, W]                         # enumFrom U \\ enumFrom Density
+    if prp == SPEED:
+        return magnitude([scheme(nxt, pos, side, env) for nxt in momentums])
+    if prp == VORTICITY:
+        pairs = [(x, y) for i, x in enumerate(momentums) for y in momentums[i + 1:]]
+
+        def component(a, b):
+            def makeDeriv(m, n):
+                return Derivative_adj(directionFromConvection(m),
+                                      lambda _st, p, s, n=n: Constant(scheme(n, p, s, env)),
+                                      EAST,                                  # "east is arbitrary here"
+                                      lambda _st, _p, _s: 1.0)
+            deriv1 = makeDeriv(a, b)
+            deriv2 = makeDeriv(b, a)
+            return val(approximateDerivative_adj(deriv1, pos, env)) - val(approximateDerivative_adj(deriv2, pos, env))
+        return magnitude([component(a, b) for a, b in pairs])
     return scheme(prp, pos, side, env)
+
+
+def magnitude(v):                      # :540-541
+    prev = 0.0
+    for nVal in v:
+        prev = prev + (nVal * nVal)
+    return math.sqrt(prev)
+
+
+def directionFromConvection(d):        # :127-131
+    return {U: X, V: Y, W: Z}[d]
 
 
 def approximateDerivative_adj(deriv, position, vs):   # :506-538
@@ -764,6 +790,30 @@ def totalDensity(env):                 # src/Main.hs:269-270
     for x in range(len(env.grids[t])):
         p = p + prop_adj(NONDIRECTIONAL, DENSITY, (x, t), CENTER, env)
     return p
+
+
+# ---------------------------------------------------------------- output slices (src/Main.hs:334-352)
+def allPositionsCurrentTime(env):      # src/Main.hs:262-263
+    return [(idx, env.currModTime) for idx in range(len(env.grids[env.currModTime]))]
+
+
+def makeRows(whole, curr, items, r, width):    # src/Main.hs:334-337 ; clause order matters: [] is tested first
+    items = list(items)
+    i = 0
+    while True:
+        if i == len(items):
+            return whole + [curr]
+        if r == 0:
+            whole, curr, r = whole + [curr], [], width
+            continue
+        curr = curr + [items[i]]
+        i += 1
+        r -= 1
+
+
+def adjGraphToGrid(vs, prp, rowLength, zLevel):    # src/Main.hs:339-346
+    picked = [c for c in allPositionsCurrentTime(vs) if getNode(vs, c).origPos[2] == zLevel]
+    return makeRows([], [], [prop_adj(NONDIRECTIONAL, prp, c, PREV, vs) for c in picked], rowLength, rowLength)
 
 
 # ---------------------------------------------------------------- known-answer inputs (src/Main.hs:79-85, :309)

@@ -427,6 +427,66 @@ double *ob_slot_ptr(ob_state *s, int slot_rel, int q) {
     return s->slot[t][q];
 }
 
+/* Output property of every cell of slot cmt-slot_rel: `prop_adj Nondirectional prp c Prev` as adjGraphToGrid
+ * evaluates it (src/Main.hs:339-346, src/SolutionDomain.hs:540-575).  Side Prev resolves to the position's own
+ * slot, and positions come from allPositionsCurrentTime, so the reference reads slot cmt (slot_rel = 0).
+ * prop follows the reference's Property enum: 0 Speed, 1 Vorticity, 2 Pressure, 3 U, 4 V, 5 W, 6 Density,
+ * 7 Temperature, 8 Mew, 9 Dye.  Vorticity differentiates at the East face ("east is arbitrary here", :561):
+ * a derivative along x is the centre difference to the East neighbour (:509-521), one along y or z the
+ * difference of the East-face values of the two neighbours in that direction (:523-536). */
+static double face_east(const ob_params *p, const double *f, int x, int y, int z) {
+    double vc = f[cidx(p, x, y, z)];
+    double up = f[cidx(p, x + 1 < p->nx ? x + 1 : x, y, z)], lo = f[cidx(p, x > 0 ? x - 1 : x, y, z)];
+    return vc + 0.5 * superbee(up - vc, vc - lo);
+}
+
+void ob_property(const ob_state *s, int prop, int slot_rel, double *out) {
+    const ob_params *p = &s->p;
+    const int nx = p->nx, ny = p->ny, nz = p->nz;
+    const int t = ((s->cmt - slot_rel) % 3 + 3) % 3;
+    const double *U = s->slot[t][0], *V = s->slot[t][1], *W = s->slot[t][2], *rho = s->slot[t][3],
+                 *T = s->slot[t][4], *dye = s->slot[t][5];
+    const double len[3] = { p->dx, p->dy, p->dz };
+    double hsame[3], hcross[3];
+    for (int d = 0; d < 3; ++d) {
+        hsame[d] = (0.0 + len[d] / 2.0) + len[d] / 2.0;
+        hcross[d] = 2.0 * (((0.0 + len[d] / 3.0) + len[d] / 3.0) + len[d] / 3.0);
+    }
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y)
+            for (int z = 0; z < nz; ++z) {
+                const size_t c = cidx(p, x, y, z);
+                double v;
+                switch (prop) {
+                case 0: v = sqrt(((0.0 + U[c] * U[c]) + V[c] * V[c]) + W[c] * W[c]); break;
+                case 1: {
+                    const int xe = x + 1 < nx ? x + 1 : x;
+                    const int yn = y + 1 < ny ? y + 1 : y, ys = y > 0 ? y - 1 : y;
+                    const int zt = z + 1 < nz ? z + 1 : z, zb = z > 0 ? z - 1 : z;
+                    const size_t e = cidx(p, xe, y, z);
+                    /* pairs (U,V), (U,W), (V,W): d_dir(a) b - d_dir(b) a */
+                    double c1 = ((V[e] - V[c]) * 1.0) / hsame[0]
+                              - ((face_east(p, U, x, yn, z) - face_east(p, U, x, ys, z)) * 1.0) / hcross[1];
+                    double c2 = ((W[e] - W[c]) * 1.0) / hsame[0]
+                              - ((face_east(p, U, x, y, zt) - face_east(p, U, x, y, zb)) * 1.0) / hcross[2];
+                    double c3 = ((face_east(p, W, x, yn, z) - face_east(p, W, x, ys, z)) * 1.0) / hcross[1]
+                              - ((face_east(p, V, x, y, zt) - face_east(p, V, x, y, zb)) * 1.0) / hcross[2];
+                    v = sqrt(((0.0 + c1 * c1) + c2 * c2) + c3 * c3);
+                    break;
+                }
+                case 2: v = (p->R * T[c]) * rho[c]; break;
+                case 3: v = U[c]; break;
+                case 4: v = V[c]; break;
+                case 5: v = W[c]; break;
+                case 6: v = rho[c]; break;
+                case 7: v = T[c]; break;
+                case 8: v = mu_of(p, T[c]); break;
+                default: v = dye[c]; break;
+                }
+                out[c] = v;
+            }
+}
+
 /* exposed for unit tests */
 double ob_superbee(double a, double b) { return superbee(a, b); }
 double ob_mu(const ob_params *p, double t) { return mu_of(p, t); }

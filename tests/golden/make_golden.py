@@ -55,7 +55,33 @@ def dump_case(name, params, fields, active, sweeps, steps):
     print("wrote", name)
 
 
+CASES = ("case_12x9x1", "case_7x6x5", "case_3x3x3_zero_vw", "case_8x7x1_zero_v")
+
+
+def dump_slices(name):
+    """Output slices (adjGraphToGrid, src/Main.hs:339-346) of every Property at every z-level, evaluated by
+    oracle_a on the state the case fixture records after its last step: the fields of slot currModTime there
+    are the inputs (key step<last>_slot0_<k> of <name>.npz), the slices are <name>_slices.npz[z<level>_p<property>]."""
+    d = np.load(os.path.join(HERE, name + ".npz"))
+    params = json.loads(str(d["params"]))
+    last = len(d["step_density"]) - 1
+    fields = [d["step%d_slot0_%d" % (last, k)] for k in range(7)]
+    nx, ny, nz = params["nx"], params["ny"], params["nz"]
+    g = A.build_graph((nx - 1, ny - 1, nz - 1), None, fields, d["active"],
+                      cellLength=[params["dx"], params["dy"], params["dz"]])
+    out = {"last_step": np.int64(last)}
+    for zl in range(nz):
+        for prp in range(10):
+            out["z%d_p%d" % (zl, prp)] = np.array(A.adjGraphToGrid(g, prp, ny, zl), np.float64)
+    np.savez_compressed(os.path.join(HERE, name + "_slices.npz"), **out)
+    print("wrote", name + "_slices")
+
+
 def main():
+    if "--slices-only" in sys.argv:         # the case fixtures stay as committed
+        for name in CASES:
+            dump_slices(name)
+        return
     kat = {
         "solveUnknown_testEquation": 0.5866666666666668,           # src/old test.txt:2
         # src/old test.txt:3, printed in reverse term order there
@@ -79,6 +105,9 @@ def main():
     # 2-D with V exactly zero
     p, fl, ac = small_case(8, 7, 1, seed=104, zero_v=True)
     dump_case("case_8x7x1_zero_v", p, fl, ac, [True, False, False], 2)
+
+    for name in CASES:
+        dump_slices(name)
 
     # first five stdout blocks of the shipped case (src/Main.hs:296-301)
     from cfd_amd import cases

@@ -13,6 +13,7 @@ from helpers import oracle_params
 from oracle import OracleB
 
 LIVE = (0, 1, 2, 3, 4, 6)       # propIndex of the oracle's six live fields
+OUTPUT = ("Speed", "Vorticity", "Pressure", "U", "V", "W", "Density", "Temperature", "Mew", "Dye")
 
 
 class OracleSlabBackend:
@@ -82,6 +83,12 @@ class OracleSlabBackend:
 
     def read_fields(self, slot_rel=0):
         return [self._own(f).copy() for f in self.ob.read_fields(slot_rel)]
+
+    def property_slice(self, prp, z_level=None):
+        k = OUTPUT.index(prp) if isinstance(prp, str) else int(prp)
+        nz = self.ob.p.nz
+        rows = self.ob.property_slice(k, (nz - 1) // 2 if z_level is None else z_level)
+        return rows[self.gl:self.gl + self.nx].copy()
 
     def sync(self):
         pass

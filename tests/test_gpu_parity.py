@@ -573,6 +573,27 @@ def test_compiled_host_prints_reference_stdout():
             assert a == b
 
 
+def test_compiled_host_prints_string_domain():
+    """cfd_main --string-domain 1: after the step block, the Vorticity slice in the reference's stringDomain
+    text form (src/Main.hs:349-352) -- equal, character for character, to the Python host's rendering of the
+    same case (Haskell `show` formatting implemented twice, C++ and Python)."""
+    import os
+    import subprocess
+    from cfd_amd import cases, output
+    from cfd_amd.solver import AdjGraph
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([os.path.join(root, "driver", "cfd_main"), "1", "--string-domain", "1"],
+                         capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stderr
+    params, fields, active = cases.reference_case()
+    g = AdjGraph(params, fields, active)
+    g.step(1)
+    want = output.string_domain(g.property_slice("Vorticity"))
+    head = "\n".join(out.stdout.split("\n")[:7])        # "starting", five lines, the blank-ish separator
+    assert out.stdout == head + "\n" + want + "\n"
+    assert want.count("\n") == params["nx"]
+
+
 def test_error_paths():
     from cfd_amd import _capi
     from cfd_amd.solver import AdjGraph
@@ -588,10 +609,82 @@ def test_error_paths():
         g.sweep_end()                       # nothing open
     with pytest.raises(_capi.CfdError):
         g.sweep_begin(True, True)           # the filter follows a sweep that does not advance time
+    for call in (lambda: g.property_slice(10), lambda: g.property_slice(-1), lambda: g.property_slice(0, 1),
+                 lambda: g.property_slice(0, -1), lambda: g.property_slice(0, 0, 3)):
+        with pytest.raises(_capi.CfdError):
+            call()
     g.sweep_begin(True)
     for call in (lambda: g.sweep_begin(False), lambda: g.sweep(True), g.time_filter, g.sweep_and_filter,
-                 lambda: g.step(1)):
+                 lambda: g.step(1), lambda: g.property_slice(0)):
         with pytest.raises(_capi.CfdError):
             call()
     g.sweep_end()
     g.sweep(False)
+
+
+# ---- output slices (adjGraphToGrid, src/Main.hs:339-346) --------------------------------------
+@pytest.mark.parametrize("shape,seed,zero_v,flags", [((12, 9, 1), 1, False, 0), ((31, 17, 1), 2, True, 4),
+                                                      ((1, 1, 1), 3, False, 0), ((7, 6, 5), 4, False, 0),
+                                                      ((9, 20, 13), 5, True, 4), ((20, 3, 1), 6, False, 2),
+                                                      ((3, 300, 2), 7, False, 0), ((300, 2, 3), 8, False, 0)])
+def test_output_slices_bit_exact(shape, seed, zero_v, flags):
+    """All ten Properties (Speed, Vorticity, Pressure, the stored ones, Mew) at several z-levels and of all
+    three time slots, after two steps: BIT-EXACT against Oracle B evaluated on the device's own fields (so
+    the bar holds for the re-associated sweep arithmetic too: the slice kernel itself keeps the reference's
+    operation order)."""
+    nx, ny, nz = shape
+    params, fields, active = small_case(nx, ny, nz, seed, zero_v)
+    g = _gpu_graph(params, fields, active, flags)
+    g.step(2)
+    for rel in range(3):
+        # an oracle whose three slots hold the device's slot `rel`: slot_rel = 0 there is that state
+        b = _oracle(params, g.read_fields(rel), active, pow_mode=1)
+        for zl in sorted({0, (nz - 1) // 2, nz - 1}):
+            for prp in range(10):
+                got = g.property_slice(prp, zl, rel)
+                assert got.shape == (nx, ny)
+                assert bits_equal(got, b.property_slice(prp, zl)), (shape, rel, zl, prp)
+    from cfd_amd.solver import OUTPUT_PROPERTIES, adjGraphToGrid
+    assert adjGraphToGrid(g, "Vorticity") == g.property_slice(OUTPUT_PROPERTIES.index("Vorticity"),
+                                                              (nz - 1) // 2).tolist()
+
+
+@pytest.mark.parametrize("name", ["case_12x9x1", "case_7x6x5", "case_3x3x3_zero_vw", "case_8x7x1_zero_v"])
+def test_output_slices_golden_fixtures_through_c_abi(name):
+    """Committed slices from the literal restatement (libm pow): nine Properties bit-exact, Mew within
+    1e-15 relative (t*sqrt(t) against pow(t, 1.5))."""
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z, s = np.load(os.path.join(gold, name + ".npz")), np.load(os.path.join(gold, name + "_slices.npz"))
+    params = json.loads(str(z["params"]))
+    params.update(device=-1, flags=0, ghost_lo=0, ghost_hi=0)
+    last = int(s["last_step"])
+    g = _gpu_graph(params, [z["step%d_slot0_%d" % (last, k)] for k in range(7)], z["active"], 0)
+    for zl in range(params["nz"]):
+        for prp in range(10):
+            got, want = g.property_slice(prp, zl), s["z%d_p%d" % (zl, prp)]
+            if prp == 8:
+                assert rel_err(got, want) <= 1e-15, (name, zl)
+            else:
+                assert bits_equal(got, want), (name, zl, prp)
+
+
+@pytest.mark.parametrize("world,shape", [(2, (12, 9, 1)), (3, (11, 40, 3))])
+def test_output_slices_of_slabs_match_single_domain(world, shape):
+    """Vorticity reaches one plane into the neighbouring slab: each virtual rank's rows (after the ghost
+    exchange SlabGraph.property_slice does) equal the undecomposed slice bit for bit."""
+    from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
+    nx, ny, nz = shape
+    params, fields, active = small_case(nx, ny, nz, seed=41)
+    ref = _gpu_graph(params, fields, active, 0)
+    peers = []
+    for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, nx, ny * nz, world)):
+        p = dict(params)
+        p["nx"] = x1 - x0
+        peers.append(SlabGraph(p, f, a, rank=r, world=world, comm=LocalComm(r, peers)))
+    bounds = [nx * r // world for r in range(world + 1)]
+    for prp in range(10):
+        want = ref.property_slice(prp)
+        for r, g in enumerate(peers):
+            assert bits_equal(g.property_slice(prp), want[bounds[r]:bounds[r + 1]]), (r, prp)

@@ -185,3 +185,55 @@ def test_haskell_show_double():
     assert sh(1.0496787532449728e-3) == "1.0496787532449728e-3"     # form seen in src/old test.txt:48
     assert sh(0.0) == "0.0" and sh(-0.0) == "-0.0" and sh(15.0) == "15.0"
     assert sh(12345678.9) == "1.23456789e7"
+
+
+# ---- output slices (adjGraphToGrid) -----------------------------------------------------------
+def _slice_inputs(name):
+    """State the slice fixture was evaluated on: slot currModTime after the case's last step."""
+    z, params, _, active = load_case(name)
+    s = np.load(os.path.join(GOLD, name + "_slices.npz"))
+    last = int(s["last_step"])
+    return s, params, [z["step%d_slot0_%d" % (last, k)] for k in range(7)], active
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_output_slices_oracle_b_matches_golden_bit_exact(name):
+    """All ten Properties at every z-level: closed form == literal restatement, bit for bit."""
+    s, params, fields, active = _slice_inputs(name)
+    b = OracleB(params, fields, active, pow_mode=0)
+    for zl in range(params["nz"]):
+        for prp in range(10):
+            want = s["z%d_p%d" % (zl, prp)]
+            got = b.property_slice(prp, zl)
+            assert got.shape == want.shape == (params["nx"], params["ny"])
+            assert bits_equal(got, want), (name, zl, prp)
+
+
+def test_output_slices_regression_oracle_a():
+    s, params, fields, active = _slice_inputs("case_3x3x3_zero_vw")
+    g = A.build_graph((2, 2, 2), None, fields, active, cellLength=[params["dx"], params["dy"], params["dz"]])
+    for prp in (A.SPEED, A.VORTICITY, A.PRESSURE, A.MEW):
+        assert bits_equal(np.array(A.adjGraphToGrid(g, prp, 3, 1)), s["z1_p%d" % prp])
+
+
+def test_output_slice_closed_forms():
+    """Speed, Pressure and Mew are cell-centre formulas; stored Properties are copies of the slot the
+    reference reads (currModTime: side Prev resolves to the position's own slot)."""
+    params, fields, active = small_case(6, 5, 4, seed=31)
+    b = OracleB(oracle_params(params), fields, active, pow_mode=0)
+    b.step(1)
+    cur = [np.asarray(f).reshape(6, 5, 4)[:, :, 1] for f in b.read_fields(0)]
+    U, V, W, rho, T = cur[0], cur[1], cur[2], cur[3], cur[4]
+    assert bits_equal(b.property_slice(0, 1), np.sqrt(((0.0 + U * U) + V * V) + W * W))
+    assert bits_equal(b.property_slice(2, 1), (params["R"] * T) * rho)
+    mu = np.array([[(params["lambda_"] * math.pow(t, 1.5)) / (t + params["suth"]) for t in row] for row in T])
+    assert bits_equal(b.property_slice(8, 1), mu)
+    for prp, k in ((3, 0), (4, 1), (5, 2), (6, 3), (7, 4), (9, 6)):
+        assert bits_equal(b.property_slice(prp, 1), cur[k])
+
+
+def test_make_rows_follows_the_reference_clause_order():
+    """makeRows (src/Main.hs:334-337): a full last row is not followed by an empty one; a ragged tail is kept."""
+    assert A.makeRows([], [], [1, 2, 3, 4], 2, 2) == [[1, 2], [3, 4]]
+    assert A.makeRows([], [], [1, 2, 3], 2, 2) == [[1, 2], [3]]
+    assert A.makeRows([], [], [], 2, 2) == [[]]

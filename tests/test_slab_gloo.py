@@ -2,7 +2,8 @@
 a slab of x-planes.  Compute is the CPU oracle (tests/slab_double.py); what is under test is
 cfd_amd.slab -- ghost flags, which plane goes to which neighbour, exchange-before-every-sweep, the
 scalar all-reduce.  Bar: every rank's owned planes equal the single-domain run BIT-FOR-BIT after
-two steps; the reduced density agrees to 1e-12 relative (summation order)."""
+two steps, and so do its rows of the ten output slices; the reduced density agrees to 1e-12
+relative (summation order)."""
 import os
 import socket
 import sys
@@ -40,7 +41,8 @@ def _rank_main(rank, world, port, shape, q):
         g = SlabGraph(p, f, a, rank=rank, world=world, comm=DistComm(rank, world), backend_cls=OracleSlabBackend)
         g.step(2)
         td = g.total_density()
-        q.put((rank, x0, x1, [g.read_fields(r) for r in range(3)], td))
+        slices = [g.property_slice(k) for k in range(10)]      # collective: exchanges the ghost planes
+        q.put((rank, x0, x1, [g.read_fields(r) for r in range(3)], td, slices))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -66,7 +68,9 @@ def test_slabs_match_single_domain(world, shape):
         p.join(timeout=60)
         assert p.exitcode == 0
     plane = ny * nz
-    for rank, x0, x1, slots, td in results:
+    for rank, x0, x1, slots, td, slices in results:
+        for k in range(10):     # output slices (Vorticity reaches into the neighbouring slabs)
+            assert bits_equal(slices[k], ref.property_slice(k, (nz - 1) // 2)[x0:x1]), (rank, k)
         for rel in range(3):
             want = ref.read_fields(rel)
             for k in range(7):
