@@ -58,24 +58,34 @@ def parse():
 
 
 def cpu_baseline(edge):
-    """Times the C restatement (oracle/, kind = "port") on a bounded sample of the same recipe."""
+    """Times the C restatement (oracle/, kind = "port") on a bounded sample of the same recipe, and on the
+    reference's own shipped configuration (301 x 151 x 1)."""
     from cfd_amd import cases
     from oracle import OracleB
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_params
     cores = min(16, os.cpu_count() or 1)
-    params, fields, active = cases.synthetic_2d(edge, edge, seed=1)
-    b = OracleB(oracle_params(params), fields, active, pow_mode=1, nthreads=cores)
-    b.step(1)                                   # untimed: first touch of the table
-    t0 = time.perf_counter()
-    nsteps = 2
-    b.step(nsteps)
-    dt = time.perf_counter() - t0
-    b.close()
-    return {"value": edge * edge * SWEEPS_PER_STEP * nsteps / dt, "unit": "cell-updates/s", "cores": cores,
-            "kind": "port",
+
+    def timed(params, fields, active, budget_s, max_steps):
+        """As many steps as fit the time budget, judged from the (untimed) first step."""
+        b = OracleB(oracle_params(params), fields, active, pow_mode=1, nthreads=cores)
+        t0 = time.perf_counter()
+        b.step(1)                               # untimed: first touch of the table
+        first = time.perf_counter() - t0
+        nsteps = max(1, min(max_steps, int(budget_s / max(first, 1e-9))))
+        t0 = time.perf_counter()
+        b.step(nsteps)
+        dt = time.perf_counter() - t0
+        b.close()
+        return params["nx"] * params["ny"] * params["nz"] * SWEEPS_PER_STEP * nsteps / dt, dt, nsteps
+
+    rate, dt, nsteps = timed(*cases.synthetic_2d(edge, edge, seed=1), 12.0, 50)
+    rate1, dt1, nsteps1 = timed(*cases.reference_case(), 3.0, 1000)
+    return {"value": rate, "unit": "cell-updates/s", "cores": cores, "kind": "port",
             "sample": "synthetic_2d %dx%d (same recipe and seed as the workload), %d steps = %d sweeps + filters, "
-                      "C restatement with OpenMP, %.1f s" % (edge, edge, nsteps, SWEEPS_PER_STEP * nsteps, dt)}
+                      "C restatement with OpenMP, %.1f s" % (edge, edge, nsteps, SWEEPS_PER_STEP * nsteps, dt),
+            "shipped_case_301x151": {"value": rate1, "unit": "cell-updates/s", "cores": cores,
+                                     "sample": "the reference's configuration, %d steps, %.1f s" % (nsteps1, dt1)}}
 
 
 def measured_traffic(workload, kernel):
