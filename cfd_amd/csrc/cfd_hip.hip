@@ -1029,8 +1029,14 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
             return NW + 2 * TZW + 2 * TYW + (a == -1 ? 2 : 0) + (b == -1 ? 1 : 0);
         return t;
     };
-    const int lN = lane_of(cy + 1 > ny - 1 ? ny - 1 : cy + 1, cz), lS = lane_of(cy - 1 < 0 ? 0 : cy - 1, cz);
-    const int lT = lane_of(cy, cz + 1 > nz - 1 ? nz - 1 : cz + 1), lB = lane_of(cy, cz - 1 < 0 ? 0 : cz - 1);
+    // LDS slot of a thread: own columns are rotated by their row number inside their row's TZW slots.
+    // Without that, the halo threads beside the tile read one tile column -- a stride of TZW doubles,
+    // two banks for the whole column -- and serialise; rotated, the column lands in distinct banks while
+    // a row still occupies one aligned run of TZW slots (any permutation of it is conflict-free).
+    auto slot_of = [=](int lane) { return lane < NW ? (lane / TZW) * TZW + ((lane % TZW + lane / TZW) % TZW) : lane; };
+    const int lN = slot_of(lane_of(cy + 1 > ny - 1 ? ny - 1 : cy + 1, cz)), lS = slot_of(lane_of(cy - 1 < 0 ? 0 : cy - 1, cz));
+    const int lT = slot_of(lane_of(cy, cz + 1 > nz - 1 ? nz - 1 : cz + 1)), lB = slot_of(lane_of(cy, cz - 1 < 0 ? 0 : cz - 1));
+    const int tw = slot_of(t);      // where this thread publishes
     const bool writer = t < NW && y < ny && z < nz;
     const int xs = x0 + bxc * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
@@ -1113,13 +1119,13 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
         }
         __syncthreads();        // every read of row j's stored values and row j-1's messages is done
 #pragma unroll
-        for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = Re[f];
+        for (int f = 0; f < NF3; ++f) lraw[f * NT + tw] = Re[f];
 #pragma unroll
-        for (int e = 0; e < NS3; ++e) { lmy[e * NT + t] = A.ms[e]; lmz[e * NT + t] = A.mb[e]; }
+        for (int e = 0; e < NS3; ++e) { lmy[e * NT + tw] = A.ms[e]; lmz[e * NT + tw] = A.mb[e]; }
 #pragma unroll
-        for (int e = 0; e < 3; ++e) lmy[(5 + e) * NT + t] = A.mn[e];
+        for (int e = 0; e < 3; ++e) lmy[(5 + e) * NT + tw] = A.mn[e];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lmz[(5 + e) * NT + t] = A.mt[e];
+        for (int e = 0; e < 4; ++e) lmz[(5 + e) * NT + tw] = A.mt[e];
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < NS3; ++e) { pq[e] = A.q[e]; pcoef[e] = A.coef[e]; }
@@ -1132,10 +1138,10 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     for (int u = 0; u < RD; ++u) load_row(clampx(j0 - 1 + u), R[u]);
     act_j = load_act(j0);
 #pragma unroll
-    for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = R[1][f];
+    for (int f = 0; f < NF3; ++f) lraw[f * NT + tw] = R[1][f];
     // the message tiles are read (and the result dropped) in the first iteration: define them
-    for (int e = 0; e < 8; ++e) lmy[e * NT + t] = 0.0;
-    for (int e = 0; e < 9; ++e) lmz[e * NT + t] = 0.0;
+    for (int e = 0; e < 8; ++e) lmy[e * NT + tw] = 0.0;
+    for (int e = 0; e < 9; ++e) lmz[e * NT + tw] = 0.0;
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): see sweep2d_stream
     int j = j0;
