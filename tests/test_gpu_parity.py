@@ -688,3 +688,155 @@ def test_output_slices_of_slabs_match_single_domain(world, shape):
         want = ref.property_slice(prp)
         for r, g in enumerate(peers):
             assert bits_equal(g.property_slice(prp), want[bounds[r]:bounds[r + 1]]), (r, prp)
+
+
+# ---- the benchmark grid itself (4096 x 4096), through size-independent properties --------------
+FULL = 4096
+
+
+def _full_size_case(seed, vary):
+    """Bench-recipe values on the full grid, varying along one axis only ('x' or 'y'); no inflow column or
+    obstacle, so that the other axis is a symmetry of the problem."""
+    from cfd_amd import cases
+    from cfd_amd.solver import make_params
+    rng = np.random.default_rng(seed)
+    u = lambda: rng.uniform(-1, 1, FULL)
+    line = [10 + 0.1 * u(), 0.1 * u(), np.zeros(FULL), 0.3 * (1 + 1e-3 * u()), 223 * (1 + 1e-3 * u()),
+            np.full(FULL, 0.1), rng.uniform(0, 1, FULL)]
+    line[6][::7] = 0.0                                           # exact zeros: the NaN -> 1 coefficient rule
+    shape = (FULL, 1) if vary == "x" else (1, FULL)
+    fields = [np.ascontiguousarray(np.broadcast_to(f.reshape(shape), (FULL, FULL))).reshape(-1) for f in line]
+    params = make_params(FULL, FULL, 1, cases.REF_DX, cases.REF_DY, cases.REF_DZ, dt=1e-7)
+    return params, fields, np.ones(FULL * FULL, np.uint8)
+
+
+@pytest.mark.parametrize("vary", ["x", "y"])
+@pytest.mark.parametrize("flags", [4, 0])
+def test_full_size_symmetry_is_kept_bitwise(vary, flags):
+    """Fields that vary along one axis only keep that symmetry exactly: after two steps on the 4096 x 4096
+    grid every line along the other axis is constant, bit for bit, in all three slots.  Each tile, chunk and
+    halo lane of the launch (plain sweep, two-sweeps kernel, fused filter) computes the same numbers from the
+    same inputs, so any indexing slip at a tile or chunk edge of the full grid shows up as a broken symmetry.
+    (Clamp-to-self at the domain ends preserves it: the clamped neighbour equals the cell.)"""
+    params, fields, active = _full_size_case(11, vary)
+    g = _gpu_graph(params, fields, active, flags)
+    g.step(2)
+    for rel in range(3):
+        for k, f in enumerate(g.read_fields(rel)):
+            a = f.reshape(FULL, FULL).view(np.uint64)
+            same = (a == a[:, :1]).all() if vary == "x" else (a == a[:1, :]).all()
+            assert same, (vary, flags, rel, PROPS[k])
+    # and the one-dimensional profile that is left equals a narrow grid's (64 cells along the symmetric axis)
+    n = 64
+    shape = (FULL, n) if vary == "x" else (n, FULL)
+    small = [np.ascontiguousarray(f.reshape(FULL, FULL)[:shape[0], :shape[1]]).reshape(-1) for f in fields]
+    p = dict(params, nx=shape[0], ny=shape[1])
+    gs = _gpu_graph(p, small, np.ones(shape[0] * shape[1], np.uint8), flags)
+    gs.step(2)
+    for rel in range(3):
+        big, sm = g.read_fields(rel), gs.read_fields(rel)
+        for k in range(7):
+            b2 = big[k].reshape(FULL, FULL)[:shape[0], :shape[1]]
+            assert bits_equal(b2, sm[k].reshape(shape)), (vary, flags, rel, PROPS[k])
+
+
+def test_full_size_default_path_against_per_cell_kernel():
+    """The benchmark workload itself (synthetic 4096 x 4096, seed 1, dt 1e-7), one step: the strict tiled kernel
+    equals the strict one-thread-per-cell kernel bit for bit; the default re-associated path (plain sweep +
+    two-sweeps kernel) stays within 3e-13 of the field scale of it (three sweeps at <= 1e-13 each)."""
+    from cfd_amd import cases
+    params, fields, active = cases.synthetic_2d(FULL, FULL, seed=1)
+    params["dt"] = 1e-7
+    ref = _gpu_graph(params, fields, active, 1)          # per-cell kernel, strict
+    ref.step(1)
+    want = [ref.read_fields(rel) for rel in range(3)]
+    ref.close()
+    g = _gpu_graph(params, fields, active, 0)
+    g.step(1)
+    for rel in range(3):
+        got = g.read_fields(rel)
+        for k in range(7):
+            assert bits_equal(got[k], want[rel][k]), (rel, PROPS[k])
+    g.close()
+    g = _gpu_graph(params, fields, active, 4)
+    g.step(1)
+    for rel in range(3):
+        assert max(field_errors(g.read_fields(rel), want[rel])) <= 3e-13, rel
+    g.close()
+
+
+def test_full_size_slabs_equal_undecomposed():
+    """4096 x 4096 cut into two slabs of 2048 planes (virtual ranks, ghost planes exchanged as aliased device
+    tensors, split sweeps with the fused filter) against the undecomposed default path: after two steps the
+    slabs equal the three-launch path bit for bit, and the two-sweeps kernel of the undecomposed run too."""
+    import torch
+    from cfd_amd import cases
+    from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
+    params, fields, active = cases.synthetic_2d(FULL, FULL, seed=2)
+    params["dt"] = 1e-7
+    params["flags"] = 4
+    ref = _gpu_graph(params, fields, active, 4)
+    ref.step(2)
+    peers = []
+    for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, FULL, FULL, 2)):
+        p = dict(params)
+        p["nx"] = x1 - x0
+        peers.append(SlabGraph(p, f, a, rank=r, world=2, comm=LocalComm(r, peers)))
+    for _ in range(2):
+        for i, st in enumerate((True, False, False)):
+            for g in peers:
+                g.backend.sweep_begin(st, i == 2)
+            for g in peers:
+                g.exchange()
+            torch.cuda.synchronize()
+            for g in peers:
+                g.backend.sweep_end()
+    half = FULL // 2 * FULL
+    for rel in range(3):
+        want = ref.read_fields(rel)
+        for r, g in enumerate(peers):
+            got = g.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(got[k], want[k][r * half:(r + 1) * half]), (r, rel, PROPS[k])
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("vary", [0, 2])
+def test_full_size_symmetry_3d(vary):
+    """512 x 512 x 512 (the 3-D benchmark grid), fields varying along one axis only (x or z): after one step of
+    the default re-associated kernels every plane across that axis is constant, bit for bit -- all tiles, halo
+    rings and chunks of the full launch compute the same numbers -- and the remaining profile equals that of
+    a grid 24 cells wide in the two symmetric directions."""
+    from cfd_amd import cases
+    from cfd_amd.solver import make_params
+    n = 512
+    rng = np.random.default_rng(13 + vary)
+    u = lambda: rng.uniform(-1, 1, n)
+    line = [10 + 0.1 * u(), 0.1 * u(), 0.1 * u(), 0.3 * (1 + 1e-3 * u()), 223 * (1 + 1e-3 * u()),
+            np.full(n, 0.1), rng.uniform(0, 1, n)]
+    line[6][::5] = 0.0
+    bshape = [1, 1, 1]
+    bshape[vary] = n
+
+    def grid_of(dims):
+        return [np.ascontiguousarray(np.broadcast_to(f.reshape(bshape), dims)).reshape(-1) for f in line]
+    dims = (n, n, n)
+    params = make_params(n, n, n, cases.REF_DX, cases.REF_DY, cases.REF_DX, dt=1e-7)
+    g = _gpu_graph(params, grid_of(dims), np.ones(n ** 3, np.uint8), 4)
+    g.step(1)
+    sdims = [24, 24, 24]
+    sdims[vary] = n
+    ps = dict(params, nx=sdims[0], ny=sdims[1], nz=sdims[2])
+    gs = _gpu_graph(ps, grid_of(tuple(sdims)), np.ones(sdims[0] * sdims[1] * sdims[2], np.uint8), 4)
+    gs.step(1)
+    first = [slice(0, 1)] * 3
+    first[vary] = slice(None)
+    for rel in range(2):
+        big, sm = g.read_fields(rel), gs.read_fields(rel)
+        for k in range(7):
+            a = big[k].reshape(dims).view(np.uint64)
+            assert (a == a[tuple(first)]).all(), (vary, rel, PROPS[k])
+            prof = big[k].reshape(dims)[tuple(first)].reshape(-1)
+            sprof = sm[k].reshape(sdims)[tuple(first)].reshape(-1)
+            assert bits_equal(prof, sprof), (vary, rel, PROPS[k])
+        del big
