@@ -7,7 +7,8 @@ One bench "step" is one reference step (runSingleStep): three forward-Euler swee
 equations plus the live time-filter pass, over the whole grid.  Workload at N = 1: the shipped
 case scaled to a 2-D 4096 x 4096 synthetic grid (cases.synthetic_2d, seed 1).  For N > 1 the
 grid is slab-decomposed along x, one process per GPU, 4096 planes per GPU (weak scaling), with
-the halo planes exchanged before every sweep.
+the halo planes exchanged before every sweep; --strong keeps the global grid fixed instead (--nx is
+then the global number of planes, e.g. --strong --nx 512 --ny 512 --nz 512).
 
 Time step: the reference ships dt = 1e-5, with which its explicit scheme amplifies every
 perturbation until the fields overflow (NaN within ~20 steps on this grid); the benchmark uses
@@ -49,6 +50,8 @@ def parse():
     ap.add_argument("--nz", type=int, default=1)
     ap.add_argument("--case", choices=("synthetic", "cavity"), default="synthetic",
                     help="cavity: lid-driven-cavity style walls, the global grid is (nx*gpus) x ny (2-D only)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --nx is the global number of x-planes, cut into --gpus slabs")
     ap.add_argument("--arith", choices=("fast", "strict"), default="fast")
     ap.add_argument("--dt", type=float, default=1e-7)
     ap.add_argument("--flags", type=int, default=0, help="extra cfd_params.flags (1 = one-thread-per-cell kernel)")
@@ -124,9 +127,17 @@ def main():
     from cfd_amd import cases
     from cfd_amd.slab import SlabGraph
 
+    global_nx = a.nx if a.strong else a.nx * world
+    if a.strong:
+        # this rank's share of the global planes (the first global_nx % world ranks hold one more)
+        if global_nx < world:
+            raise SystemExit("--strong: fewer x-planes than ranks")
+        a.nx = global_nx // world + (1 if rank < global_nx % world else 0)
     two_d = a.nz == 1
     if two_d and a.case == "cavity":
-        params, fields, active = cases.cavity_2d_slab(a.nx * world, a.ny, a.nx * rank, a.nx * (rank + 1))
+        first = sum(global_nx // world + (1 if r < global_nx % world else 0) for r in range(rank)) if a.strong \
+            else a.nx * rank
+        params, fields, active = cases.cavity_2d_slab(global_nx, a.ny, first, first + a.nx)
     elif two_d:
         params, fields, active = cases.synthetic_2d(a.nx, a.ny, seed=1 + rank)
     else:
@@ -162,7 +173,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    cells_per_gpu = a.nx * a.ny * a.nz
+    cells_per_gpu = a.nx * a.ny * a.nz                   # this rank's cells (rank 0 reports)
+    total_cells = global_nx * a.ny * a.nz
     final_density = g.total_density()
 
     strict = None
@@ -189,7 +201,7 @@ def main():
                                                     else BYTES_PER_UPDATE_3D) / (kms / 1e3 / max(kl, 1)) / 1e9}
         gs.close()
     del fields
-    updates = cells_per_gpu * world * SWEEPS_PER_STEP * a.steps
+    updates = total_cells * SWEEPS_PER_STEP * a.steps
     bytes_per_update = BYTES_PER_UPDATE_2D if two_d else BYTES_PER_UPDATE_3D
     # Launch kinds in the timed region, per step: three plain sweeps; or two plus one fused with the filter; or one
     # plain sweep plus one launch that does two sweeps and the filter in one pass.  At N > 1 a sweep is two or three
@@ -220,6 +232,8 @@ def main():
     workload = ("cavity_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if (two_d and a.case == "cavity") else \
         ("synthetic_2d %dx%dx1 per GPU" % (a.nx, a.ny)) if two_d else \
         ("synthetic_3d %dx%dx%d per GPU" % (a.nx, a.ny, a.nz))
+    if a.strong:
+        workload += " (rank 0's share of %d global x-planes)" % global_nx
     kernel_name = base_name
     out = {
         "metric": "fp64 cell-updates/sec",
@@ -230,7 +244,7 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if a.strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
