@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcfdhip.so")
+# CFD_LIB: another build of the same library (A/B timing of kernel changes)
+LIB_PATH = os.environ.get("CFD_LIB") or os.path.join(_HERE, "libcfdhip.so")
 
 CFD_NPROP = 7
 CFD_OK, CFD_E_ARG, CFD_E_DEVICE, CFD_E_MEMORY, CFD_E_STATE = 0, -1, -2, -3, -4

@@ -151,10 +151,16 @@ CFD_HD double select(lane_mask m, double x, double y) {
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((unsigned)(yb >> 32)), "v"((unsigned)(xb >> 32)), "s"(m));
     return from_bits((long long)(((unsigned long long)hi << 32) | lo));
 }
+CFD_HD unsigned select_u32(lane_mask m, unsigned x, unsigned y) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(y), "v"(x), "s"(m));
+    return r;
+}
 #else
 typedef bool lane_mask;
 CFD_HD lane_mask mask_of(bool c) { return c; }
 CFD_HD double select(lane_mask m, double x, double y) { return m ? x : y; }
+CFD_HD unsigned select_u32(lane_mask m, unsigned x, unsigned y) { return m ? x : y; }
 #endif
 
 // F * (1/phi), with the reference's NaN -> 1 substitution.
