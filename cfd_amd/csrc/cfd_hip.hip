@@ -752,7 +752,7 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
 #pragma unroll
         for (int f = 0; f < NF2; ++f) { rn[f] = lraw1[f][lnc]; rs[f] = lraw1[f][lsc]; }
         StreamA2 A;
-        phaseA2s(K, Rc, hx, rn, rs, mask_of(act1 != 0), A);
+        phaseA2s<SelPlain>(K, Rc, hx, rn, rs, act1 != 0, A);
         stream_west(A.q, A.coef, mw1, mw1D);
         double vnew[NF2];                                    // v1(j-1)
         vnew[F2_U] = stream_finish(q1[S2_U], c1[S2_U], A.me[S2_U], lmsg1[0][lnc], lmsg1[4][lsc]);
@@ -762,16 +762,16 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
         vnew[F2_RHO] = rho1;
         const int r1 = j - 1;
         {
-            const lane_mask above = mask_of(r1 > xhi1);      // above the domain: a copy of the last defined row
+            const bool above = r1 > xhi1;            // above the domain: a copy of the last defined row
 #pragma unroll
-            for (int f = 0; f < NF2; ++f) vnew[f] = select(above, Vc[f], vnew[f]);
+            for (int f = 0; f < NF2; ++f) vnew[f] = above ? Vc[f] : vnew[f];
         }
 #pragma unroll
         for (int f = 0; f < NF2; ++f) Ve[f] = vnew[f];
         {
-            const lane_mask below = mask_of(r1 == xlo1);     // below the domain: copies of the first defined row
+            const bool below = r1 == xlo1;          // below the domain: copies of the first defined row
 #pragma unroll
-            for (int f = 0; f < NF2; ++f) { Vc[f] = select(below, vnew[f], Vc[f]); Vw[f] = select(below, vnew[f], Vw[f]); }
+            for (int f = 0; f < NF2; ++f) { Vc[f] = below ? vnew[f] : Vc[f]; Vw[f] = below ? vnew[f] : Vw[f]; }
         }
         // ---- stage 2: phase A of row j-2 on the once-swept values, then finish row j-3
         double hx2[NF2], rn2[NF2], rs2[NF2];
@@ -779,15 +779,15 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
 #pragma unroll
         for (int f = 0; f < NF2; ++f) { rn2[f] = lraw2[f][lnc]; rs2[f] = lraw2[f][lsc]; }
         StreamA2 B;
-        phaseA2s(K, Vc, hx2, rn2, rs2, mask_of(act2 != 0), B);
+        phaseA2s<SelPlain>(K, Vc, hx2, rn2, rs2, act2 != 0, B);
         {   // clamp-to-self on the West side of the second sweep
-            const lane_mask fm = mask_of(j - 2 == a2first);
-            mw2[0] = select(fm, B.mw[0], mw2[0]); mw2[1] = select(fm, B.mw[1], mw2[1]);
-            mw2[2] = select(fm, B.mw[2], mw2[2]); mw2D = select(fm, B.me[S2_DYE], mw2D);
+            const bool fm = j - 2 == a2first;
+            mw2[0] = fm ? B.mw[0] : mw2[0]; mw2[1] = fm ? B.mw[1] : mw2[1];
+            mw2[2] = fm ? B.mw[2] : mw2[2]; mw2D = fm ? B.me[S2_DYE] : mw2D;
         }
         stream_west(B.q, B.coef, mw2, mw2D);
         {
-            const unsigned vs = select_u32(mask_of(xo >= xs && xo < xe), vst, 0xFFFFFFF0u);
+            const unsigned vs = (xo >= xs && xo < xe) ? vst : 0xFFFFFFF0u;
             const double nU = stream_finish(q2[S2_U], c2[S2_U], B.me[S2_U], lmsg2[0][lnc], lmsg2[4][lsc]);
             const double nV = stream_finish(q2[S2_V], c2[S2_V], B.me[S2_V], lmsg2[1][lnc], lmsg2[5][lsc]);
             const double nT = stream_finish(q2[S2_T], c2[S2_T], B.me[S2_T], lmsg2[2][lnc], lmsg2[2][lsc]);
