@@ -1,12 +1,13 @@
 // libcfdhip.so -- fp64 HIP kernels (gfx950) and the C ABI declared in include/cfd_hip.h.
 //
 // Device layout ("plane-interleaved structure of arrays"): one time slot is
-//     value(f, x, y, z) = slot[ ((x+1)*NF + f) * (ny*nz) + y*nz + z ]
+//     value(f, x, y, z) = slot[ ((x+2)*NF + f) * (ny*nz) + y*nz + z ]
 // i.e. for every x-plane the NF live fields lie back to back, each as ny*nz contiguous
 // doubles.  Lanes run along the fastest index (y*nz+z), so accesses coalesce exactly as in a
 // plain structure of arrays, while a whole x-plane of all fields is ONE contiguous run: the
-// slab halo that a neighbouring GPU needs is a single message with no pack kernel.  Plane -1
-// and plane nx are ghost planes (used only when a neighbouring slab exists).
+// slab halo that a neighbouring GPU needs is a single message with no pack kernel.  Planes -2, -1
+// and nx, nx+1 are ghost planes (used only when a neighbouring slab exists: one per side for a
+// single sweep, two for the kernel that does two sweeps in one pass).
 //
 // Four buffers per handle: the three time slots of the reference plus one scratch slot that
 // receives a sweep which does not advance time (the reference rebuilds slot t from a snapshot
@@ -25,6 +26,8 @@
 #include "sweep_math.h"
 
 using namespace cfd;
+
+static constexpr int GHOST = 2;      // ghost x-planes allocated on either side of the owned planes
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -56,10 +59,11 @@ struct cfd_handle {
     int nf;                 // live fields on the device: 5 (2-D, W == 0) or 6
     bool two_d;
     size_t plane;           // ny*nz
-    size_t slot_elems;      // nf * (nx+2) * plane
+    size_t slot_elems;      // nf * (nx + 2*GHOST) * plane
     double* buf[4];         // three time slots + scratch
     int map[4];             // map[t] = buffer holding time slot t (t = 0..2); map[3] = scratch
-    uint8_t* d_active;      // (nx+2) * plane bytes, ghost planes zero
+    uint8_t* d_active;      // (nx + 2*GHOST) * plane bytes; ghost planes zero until cfd_set_ghost_active
+    bool ghost_mask_set;    // the masks of planes -1 and nx have been supplied
     double* d_partial;      // reduction partials
     int n_partial;
     std::vector<double> mew;   // stored Mew: set at creation, never read by the update
@@ -98,7 +102,7 @@ static const int kProp3[6] = {0, 1, 2, 3, 4, 6};
 
 static inline double* slot_base(const cfd_handle* h, int t) {
     // points at plane x = 0, field 0
-    return h->buf[h->map[t]] + (size_t)h->nf * h->plane;
+    return h->buf[h->map[t]] + (size_t)GHOST * h->nf * h->plane;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1318,7 +1322,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
     // queueing gaps.
     hipEvent_t ea = h->timing ? ev.a : nullptr, eb = h->timing ? ev.b : nullptr;
     const bool fast = (p.flags & CFD_FLAG_FAST_MATH) != 0;
-    const uint8_t* act = h->d_active + h->plane;
+    const uint8_t* act = h->d_active + GHOST * h->plane;
     if (h->two_d && (p.flags & CFD_FLAG_SIMPLE_KERNEL)) {
         dim3 block(64), grid((p.ny + 63) / 64, x1 - x0);
         if (fast)
@@ -1462,8 +1466,11 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
 // Two in-place sweeps (+ filter) in one pass; only where pair_ok(h).
 static bool pair_ok(const cfd_handle* h) {
     const cfd_params& p = h->p;
-    return h->two_d && (p.flags & CFD_FLAG_FAST_MATH) && !(p.flags & CFD_FLAG_SIMPLE_KERNEL) && !p.ghost_lo &&
-           !p.ghost_hi && h->pair_enabled && h->variant < 0;      // only beside the default launch shape
+    // beside the default launch shape only; a slab needs the masks of its ghost planes and at least two planes
+    // (the planes it sends two-deep to a neighbour must be its own)
+    const bool ghosts = p.ghost_lo || p.ghost_hi;
+    return h->two_d && (p.flags & CFD_FLAG_FAST_MATH) && !(p.flags & CFD_FLAG_SIMPLE_KERNEL) && h->pair_enabled &&
+           h->variant < 0 && (!ghosts || (h->ghost_mask_set && p.nx >= 2));
 }
 
 static int launch_pair(cfd_handle* h, const double* src, double* dst, const double* fpp, double* fprev) {
@@ -1479,16 +1486,19 @@ static int launch_pair(cfd_handle* h, const double* src, double* dst, const doub
         }
     }
     hipEvent_t ea = h->timing ? ev.a : nullptr, eb = h->timing ? ev.b : nullptr;
-    const uint8_t* act = h->d_active + h->plane;
+    const uint8_t* act = h->d_active + GHOST * h->plane;
     const int ch = h->pair_chunk;
     constexpr int NT = 256, WC = 240;
     dim3 block(NT), grid((p.ny + WC - 1) / WC, (p.nx + ch - 1) / ch);
+    // with a neighbouring slab: stored values reach two ghost planes out, once-swept values one
+    const int xlo = p.ghost_lo ? -2 : 0, xhi = p.ghost_hi ? p.nx + 1 : p.nx - 1;
+    const int xlo1 = p.ghost_lo ? -1 : 0, xhi1 = p.ghost_hi ? p.nx : p.nx - 1;
     if (fpp)
         hipExtLaunchKernelGGL((sweep2d_pair<NT, 2, WC, true>), grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
-                              act, 0, p.nx, p.ny, 0, p.nx - 1, 0, p.nx - 1, ch, fpp, fprev);
+                              act, 0, p.nx, p.ny, xlo, xhi, xlo1, xhi1, ch, fpp, fprev);
     else
         hipExtLaunchKernelGGL((sweep2d_pair<NT, 2, WC, false>), grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
-                              act, 0, p.nx, p.ny, 0, p.nx - 1, 0, p.nx - 1, ch, fpp, fprev);
+                              act, 0, p.nx, p.ny, xlo, xhi, xlo1, xhi1, ch, fpp, fprev);
     HIP_TRY(hipGetLastError());
     if (h->timing) { ev.kind = 2; h->ev_used.push_back(ev); }
     return CFD_OK;
@@ -1568,7 +1578,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     }
     h->two_d = (p->nz == 1) && w_zero && !(p->flags & CFD_FLAG_FORCE_3D);
     h->nf = h->two_d ? 5 : 6;
-    h->slot_elems = (size_t)h->nf * (p->nx + 2) * h->plane;
+    h->slot_elems = (size_t)h->nf * (p->nx + 2 * GHOST) * h->plane;
     h->K = make_consts(p->dx, p->dy, p->dz, p->dt, p->lambda, p->suth, p->R, p->cv, p->k, p->dye_f);
     h->KF = make_fast_consts(h->K, p->dx, p->dy, p->dz);
     h->march3_ok = (double)NF3 * (double)h->plane * 8.0 < 4.0e9;
@@ -1592,6 +1602,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->variant = -1;
     if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
+    h->ghost_mask_set = false;
     h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;
     h->timing = false; h->t_ms[0] = h->t_ms[1] = h->t_ms[2] = 0.0; h->t_launches[0] = h->t_launches[1] = h->t_launches[2] = 0;
     h->mew.assign(fields[5], fields[5] + n);
@@ -1611,16 +1622,16 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
         CREATE_TRY(hipMalloc((void**)&h->buf[i], h->slot_elems * sizeof(double)));
         CREATE_TRY(hipMemsetAsync(h->buf[i], 0, h->slot_elems * sizeof(double), h->stream));
     }
-    CREATE_TRY(hipMalloc((void**)&h->d_active, (size_t)(p->nx + 2) * h->plane));
-    CREATE_TRY(hipMemsetAsync(h->d_active, 0, (size_t)(p->nx + 2) * h->plane, h->stream));
+    CREATE_TRY(hipMalloc((void**)&h->d_active, (size_t)(p->nx + 2 * GHOST) * h->plane));
+    CREATE_TRY(hipMemsetAsync(h->d_active, 0, (size_t)(p->nx + 2 * GHOST) * h->plane, h->stream));
     h->n_partial = 1024;
     CREATE_TRY(hipMalloc((void**)&h->d_partial, (h->n_partial + 1) * sizeof(double)));
-    CREATE_TRY(hipMemcpyAsync(h->d_active + h->plane, active, n, hipMemcpyHostToDevice, h->stream));
+    CREATE_TRY(hipMemcpyAsync(h->d_active + GHOST * h->plane, active, n, hipMemcpyHostToDevice, h->stream));
     // slot 0 from the host fields, plane-interleaved; then slots 1, 2 and scratch as device copies
     const int* prop = h->two_d ? kProp2 : kProp3;
     const size_t row = h->plane * sizeof(double);
     for (int f = 0; f < h->nf; ++f) {
-        double* d = h->buf[0] + ((size_t)h->nf + f) * h->plane;
+        double* d = h->buf[0] + ((size_t)GHOST * h->nf + f) * h->plane;
         CREATE_TRY(hipMemcpy2DAsync(d, (size_t)h->nf * row, fields[prop[f]], row, row, p->nx,
                                     hipMemcpyHostToDevice, h->stream));
     }
@@ -1662,7 +1673,7 @@ int cfd_time_filter(cfd_handle* h) {
     const unsigned always = h->two_d ? ((1u << F2_RHO) | (1u << F2_T)) : ((1u << 3) | (1u << 4));
     dim3 block(256), grid((unsigned)((h->plane + 255) / 256), h->nf, h->p.nx);
     hipLaunchKernelGGL(time_filter_kernel, grid, block, 0, h->stream, slot_base(h, h->cmt), slot_base(h, tc),
-                       slot_base(h, tb), h->d_active + h->plane, (long)h->plane, h->nf, always);
+                       slot_base(h, tb), h->d_active + GHOST * h->plane, (long)h->plane, h->nf, always);
     HIP_TRY(hipGetLastError());
     return CFD_OK;
 }
@@ -1700,6 +1711,10 @@ int cfd_sweep_pair_and_filter(cfd_handle* h) {
     if (h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_pair_and_filter: a split sweep is open (call cfd_sweep_end first)");
     HIP_TRY(hipSetDevice(h->device));
     if (!pair_ok(h)) {
+        // Two separate sweeps need the ghost planes refreshed in between, which only the caller can do.
+        if (h->p.ghost_lo || h->p.ghost_hi)
+            return fail(CFD_E_STATE, "cfd_sweep_pair_and_filter: not available for this slab (see cfd_pair_available); "
+                                     "run cfd_sweep and cfd_sweep_and_filter with an exchange before each");
         int rc = cfd_sweep(h, 0);
         return rc ? rc : cfd_sweep_and_filter(h);
     }
@@ -1779,7 +1794,12 @@ int cfd_step(cfd_handle* h, int nsteps) {
         // the third sweep's kernel where that kernel supports it, as its own launch otherwise.
         int rc;
         if ((rc = cfd_sweep(h, 1))) return rc;
-        if ((rc = cfd_sweep_pair_and_filter(h))) return rc;
+        if (pair_ok(h) || !(h->p.ghost_lo || h->p.ghost_hi)) {
+            if ((rc = cfd_sweep_pair_and_filter(h))) return rc;
+        } else {
+            if ((rc = cfd_sweep(h, 0))) return rc;
+            if ((rc = cfd_sweep_and_filter(h))) return rc;
+        }
     }
     return CFD_OK;
 }
@@ -1859,16 +1879,45 @@ int cfd_time(cfd_handle* h, int* cmt, int* cat) {
     return CFD_OK;
 }
 
-int cfd_halo_planes(cfd_handle* h, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
-                    size_t* plane_bytes) {
-    if (!h) return fail(CFD_E_ARG, "cfd_halo_planes: null handle");
+int cfd_halo_planes_depth(cfd_handle* h, int depth, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
+                          size_t* bytes) {
+    if (!h) return fail(CFD_E_ARG, "cfd_halo_planes_depth: null handle");
+    if (depth < 1 || depth > GHOST) return fail(CFD_E_ARG, "cfd_halo_planes_depth: depth must be 1 or 2");
+    if (depth > h->p.nx) return fail(CFD_E_ARG, "cfd_halo_planes_depth: the slab has fewer planes than the depth asked for");
     double* base = slot_base(h, h->cmt);
     const size_t pe = (size_t)h->nf * h->plane;
     if (send_lo) *send_lo = base;
-    if (send_hi) *send_hi = base + (size_t)(h->p.nx - 1) * pe;
-    if (recv_lo) *recv_lo = h->p.ghost_lo ? (void*)(base - pe) : nullptr;
+    if (send_hi) *send_hi = base + (size_t)(h->p.nx - depth) * pe;
+    if (recv_lo) *recv_lo = h->p.ghost_lo ? (void*)(base - (size_t)depth * pe) : nullptr;
     if (recv_hi) *recv_hi = h->p.ghost_hi ? (void*)(base + (size_t)h->p.nx * pe) : nullptr;
-    if (plane_bytes) *plane_bytes = pe * sizeof(double);
+    if (bytes) *bytes = (size_t)depth * pe * sizeof(double);
+    return CFD_OK;
+}
+
+int cfd_halo_planes(cfd_handle* h, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
+                    size_t* plane_bytes) {
+    if (!h) return fail(CFD_E_ARG, "cfd_halo_planes: null handle");
+    return cfd_halo_planes_depth(h, 1, send_lo, send_hi, recv_lo, recv_hi, plane_bytes);
+}
+
+int cfd_set_ghost_active(cfd_handle* h, const uint8_t* lo_plane, const uint8_t* hi_plane) {
+    if (!h) return fail(CFD_E_ARG, "cfd_set_ghost_active: null handle");
+    if ((h->p.ghost_lo && !lo_plane) || (h->p.ghost_hi && !hi_plane))
+        return fail(CFD_E_ARG, "cfd_set_ghost_active: a mask plane is needed on every side that has a ghost plane");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_set_ghost_active: a split sweep is open (call cfd_sweep_end first)");
+    HIP_TRY(hipSetDevice(h->device));
+    uint8_t* own = h->d_active + GHOST * h->plane;
+    if (h->p.ghost_lo) HIP_TRY(hipMemcpyAsync(own - h->plane, lo_plane, h->plane, hipMemcpyHostToDevice, h->stream));
+    if (h->p.ghost_hi)
+        HIP_TRY(hipMemcpyAsync(own + (size_t)h->p.nx * h->plane, hi_plane, h->plane, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->ghost_mask_set = true;
+    return CFD_OK;
+}
+
+int cfd_pair_available(cfd_handle* h, int* available) {
+    if (!h || !available) return fail(CFD_E_ARG, "cfd_pair_available: null pointer");
+    *available = pair_ok(h) ? 1 : 0;
     return CFD_OK;
 }
 

@@ -9,6 +9,8 @@ Per sweep:  start the exchange of the current slot's ghost planes, launch every 
             ghost plane, wait for the exchange, launch the first / last plane (interior compute
             overlaps the transfer).
 Per step:   3 such sweeps; the live filter pass needs no halo and is fused into the third sweep.
+            Where the library can do the second and third sweep in one pass (2-D, re-associated
+            arithmetic), the step is one such sweep, one exchange of TWO planes per side, and that pass.
 Reduction:  local tree sum of Density, then one all-reduce of a single double.
 
 Domain ends keep the reference's clamp-to-self rule (no wrap-around): rank 0 has no low
@@ -40,25 +42,39 @@ class GpuBackend:
         import torch
         self._torch = torch
         self.graph = AdjGraph(params, fields, active)
+        plane = params["ny"] * params["nz"]
+        act = np.ascontiguousarray(active, dtype=np.uint8).reshape(-1)
+        self._first_mask, self._last_mask = act[:plane].copy(), act[-plane:].copy()
         # run on torch's current stream so that torch.distributed's stream ordering covers the kernels
         self.graph.set_stream(torch.cuda.current_stream().cuda_stream)
         self._cache = {}
 
-    def halo_tensors(self):
-        ptrs, nbytes = self.graph.halo_planes()
+    def halo_tensors(self, depth=1):
+        ptrs, nbytes = self.graph.halo_planes(depth)
         out = []
         for p in ptrs:
             if not p:
                 out.append(None)
                 continue
-            t = self._cache.get(p)
+            t = self._cache.get((p, nbytes))
             if t is None:
                 t = self._torch.as_tensor(_DeviceSpan(p, nbytes), device="cuda")
-                self._cache[p] = t
+                self._cache[(p, nbytes)] = t
             out.append(t)
         return out
 
-    def halo_commit(self):
+    def boundary_active(self):
+        """This slab's masks of its first and last plane (host arrays)."""
+        return self._first_mask, self._last_mask
+
+    def mask_tensor(self, plane=None):
+        """A device tensor for exchanging a mask plane: a copy of `plane`, or an empty one to receive into."""
+        torch = self._torch
+        if plane is None:
+            return torch.empty(self._first_mask.size, dtype=torch.uint8, device="cuda")
+        return torch.from_numpy(np.ascontiguousarray(plane)).cuda()
+
+    def halo_commit(self, depth=1):
         """Received planes land directly in the time slot; nothing to unpack."""
 
     def scalar_tensor(self, v):
@@ -75,14 +91,50 @@ class DistComm:
         import torch.distributed as dist
         self.dist, self.rank, self.world = dist, rank, world
 
-    def exchange_start(self, backend):
-        """Posts the sends of this rank's first / last owned plane and the receives into its ghost
+    def _neighbour_ops(self, send_lo, send_hi, recv_lo, recv_hi):
+        dist = self.dist
+        ops = []
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.isend, send_lo, self.rank - 1))
+            ops.append(dist.P2POp(dist.irecv, recv_lo, self.rank - 1))
+        if self.rank < self.world - 1:
+            ops.append(dist.P2POp(dist.isend, send_hi, self.rank + 1))
+            ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
+        return ops
+
+    def exchange_masks(self, backend):
+        """The neighbours' masks of the planes next to this slab: (lo, hi) host arrays, None at a domain end."""
+        if self.world == 1:
+            return None, None
+        first, last = backend.boundary_active()
+        recv_lo = backend.mask_tensor() if self.rank > 0 else None
+        recv_hi = backend.mask_tensor() if self.rank < self.world - 1 else None
+        for req in self.dist.batch_isend_irecv(self._neighbour_ops(backend.mask_tensor(first), backend.mask_tensor(last),
+                                                                   recv_lo, recv_hi)):
+            req.wait()
+        host = lambda t: None if t is None else t.cpu().numpy()
+        return host(recv_lo), host(recv_hi)
+
+    def agree_pair(self, slab):
+        slab.set_ghost_masks()
+        return self.all_min(slab.backend, int(slab.backend.pair_available()))
+
+    def all_min(self, backend, v):
+        """Smallest of the ranks' integers."""
+        if self.world == 1:
+            return int(v)
+        t = backend.scalar_tensor(float(v))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
+
+    def exchange_start(self, backend, depth=1):
+        """Posts the sends of this rank's first / last `depth` owned planes and the receives into its ghost
         planes; returns the requests.  With the nccl backend the transfers run on the process
         group's own stream, ordered after the work already queued on the current stream."""
         if self.world == 1:
             return []
         dist = self.dist
-        send_lo, send_hi, recv_lo, recv_hi = backend.halo_tensors()
+        send_lo, send_hi, recv_lo, recv_hi = backend.halo_tensors(depth)
         ops = []
         if self.rank > 0:
             ops.append(dist.P2POp(dist.isend, send_lo, self.rank - 1))
@@ -92,14 +144,14 @@ class DistComm:
             ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
         return dist.batch_isend_irecv(ops)
 
-    def exchange_wait(self, backend, reqs):
+    def exchange_wait(self, backend, reqs, depth=1):
         """Orders the current stream (nccl) or the host (gloo) after the transfers."""
         for req in reqs:
             req.wait()
-        backend.halo_commit()
+        backend.halo_commit(depth)
 
-    def exchange(self, backend):
-        self.exchange_wait(backend, self.exchange_start(backend))
+    def exchange(self, backend, depth=1):
+        self.exchange_wait(backend, self.exchange_start(backend, depth), depth)
 
     def all_sum(self, backend, v):
         if self.world == 1:
@@ -117,21 +169,32 @@ class LocalComm:
         self.rank, self.peers = rank, peers
         self.world = None
 
-    def exchange(self, backend):
+    def exchange(self, backend, depth=1):
         # pull model: every rank copies what it needs from its neighbours' send planes
         me = self.rank
-        _, _, recv_lo, recv_hi = backend.halo_tensors()
+        _, _, recv_lo, recv_hi = backend.halo_tensors(depth)
         if me > 0:
-            recv_lo.copy_(self.peers[me - 1].backend.halo_tensors()[1])
+            recv_lo.copy_(self.peers[me - 1].backend.halo_tensors(depth)[1])
         if me < len(self.peers) - 1:
-            recv_hi.copy_(self.peers[me + 1].backend.halo_tensors()[0])
-        backend.halo_commit()
+            recv_hi.copy_(self.peers[me + 1].backend.halo_tensors(depth)[0])
+        backend.halo_commit(depth)
 
-    def exchange_start(self, backend):
+    def exchange_start(self, backend, depth=1):
         return []
 
-    def exchange_wait(self, backend, reqs):
-        self.exchange(backend)
+    def exchange_wait(self, backend, reqs, depth=1):
+        self.exchange(backend, depth)
+
+    def exchange_masks(self, backend):
+        me = self.rank
+        lo = self.peers[me - 1].backend.boundary_active()[1] if me > 0 else None
+        hi = self.peers[me + 1].backend.boundary_active()[0] if me < len(self.peers) - 1 else None
+        return lo, hi
+
+    def agree_pair(self, slab):
+        for g in self.peers:
+            g.set_ghost_masks()
+        return all(g.backend.pair_available() for g in self.peers)
 
     def all_sum(self, backend, v):
         raise NotImplementedError("sum over virtual ranks is done by the caller")
@@ -140,7 +203,9 @@ class LocalComm:
 class SlabGraph:
     """One rank's slab.  `fields` / `active` hold this rank's owned planes only."""
 
-    def __init__(self, params, fields, active, rank=0, world=1, comm=None, backend_cls=GpuBackend):
+    def __init__(self, params, fields, active, rank=0, world=1, comm=None, backend_cls=GpuBackend, pair=True):
+        """pair=False keeps the three-sweeps-per-step form (one-plane halos only) even where the one-pass
+        tail is available; every rank must pass the same value."""
         p = dict(params)
         p["ghost_lo"] = 1 if rank > 0 else 0
         p["ghost_hi"] = 1 if rank < world - 1 else 0
@@ -148,6 +213,25 @@ class SlabGraph:
         self.backend = backend_cls(p, fields, active)
         self.graph = self.backend.graph if hasattr(self.backend, "graph") else self.backend
         self.comm = comm if comm is not None else DistComm(rank, world)
+        self._masks_set = False
+        self._use_pair = None if pair else False
+
+    def set_ghost_masks(self):
+        """Hands the backend the neighbouring slabs' masks of the planes next to this slab (once; a
+        collective with DistComm)."""
+        if not self._masks_set and self.world > 1:
+            lo, hi = self.comm.exchange_masks(self.backend)
+            self.backend.set_ghost_active(lo, hi)
+        self._masks_set = True
+
+    def use_pair(self):
+        """Whether the tail of a step (second and third sweep + filter) runs as one pass over memory with a
+        two-plane halo.  Neighbours must exchange the same depth, so the ranks decide together, once
+        (a collective with DistComm)."""
+        if self._use_pair is None:
+            self._use_pair = self.world > 1 and hasattr(self.backend, "pair_available") and \
+                bool(self.comm.agree_pair(self))
+        return self._use_pair
 
     # the reference's verbs, slab-aware
     def exchange(self):
@@ -177,10 +261,15 @@ class SlabGraph:
         if self.world == 1 and hasattr(self.backend, "step"):
             self.backend.step(nsteps)       # undecomposed: the library's own step (second and third sweep in one pass)
             return self
+        pair = self.use_pair()
         for _ in range(nsteps):
             self._sweep(True, False)
-            self._sweep(False, False)
-            self._sweep(False, True)
+            if pair:
+                self.comm.exchange(self.backend, depth=2)       # two planes per side: both remaining sweeps
+                self.backend.sweep_pair_and_filter()
+            else:
+                self._sweep(False, False)
+                self._sweep(False, True)
         return self
 
     def total_density(self):

@@ -164,12 +164,33 @@ class AdjGraph:
         check(self._lib.cfd_kernel_timing(self._h, int(kind), ctypes.byref(ms), ctypes.byref(n), int(bool(reset))))
         return ms.value, n.value
 
-    def halo_planes(self):
-        """Device addresses (ints, 0 for none) of send_lo, send_hi, recv_lo, recv_hi and the plane size in bytes."""
+    def halo_planes(self, depth=1):
+        """Device addresses (ints, 0 for none) of send_lo, send_hi, recv_lo, recv_hi for a halo `depth` planes
+        deep, and the size of each range in bytes."""
         p = [ctypes.c_void_p() for _ in range(4)]
         nbytes = ctypes.c_size_t()
-        check(self._lib.cfd_halo_planes(self._h, *[ctypes.byref(x) for x in p], ctypes.byref(nbytes)))
+        check(self._lib.cfd_halo_planes_depth(self._h, int(depth), *[ctypes.byref(x) for x in p],
+                                              ctypes.byref(nbytes)))
         return [x.value or 0 for x in p], nbytes.value
+
+    def set_ghost_active(self, lo_plane, hi_plane):
+        """Masks of the neighbouring slabs' planes next to this slab (None where there is no neighbour)."""
+        def arr(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+        lo, hi = arr(lo_plane), arr(hi_plane)
+        plane = self._p.ny * self._p.nz
+        for a in (lo, hi):
+            if a is not None and a.size != plane:
+                raise ValueError("a mask plane has ny*nz entries")
+        check(self._lib.cfd_set_ghost_active(self._h, None if lo is None else lo.ctypes.data,
+                                             None if hi is None else hi.ctypes.data))
+        return self
+
+    def pair_available(self):
+        """True if sweep_pair_and_filter runs as one pass over memory for this graph as it is now."""
+        v = ctypes.c_int()
+        check(self._lib.cfd_pair_available(self._h, ctypes.byref(v)))
+        return bool(v.value)
 
     def stream(self):
         s = ctypes.c_void_p()

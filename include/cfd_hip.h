@@ -119,9 +119,14 @@ int cfd_time_filter(cfd_handle *h);
 int cfd_sweep_and_filter(cfd_handle *h);
 
 /* The tail of runSingleStep (src/Main.hs:194-197 with next == 1 and next == 2): two sweeps that do not
- * advance time, then correctPrevTime.  For 2-D grids with CFD_FLAG_FAST_MATH and no ghost planes the two
- * sweeps run in one pass over memory (the intermediate field never reaches HBM); otherwise this is
- * cfd_sweep(h, 0) followed by cfd_sweep_and_filter(h).  Results are identical either way. */
+ * advance time, then correctPrevTime.  For 2-D grids with CFD_FLAG_FAST_MATH the two sweeps run in one
+ * pass over memory (the intermediate field never reaches HBM); otherwise this is cfd_sweep(h, 0)
+ * followed by cfd_sweep_and_filter(h).  Results are identical either way.
+ * Slabs (handles with ghost planes): the one-pass form reads TWO ghost planes of the current slot on
+ * every side that has a neighbour (cfd_halo_planes_depth with depth 2, exchanged before the call) and the
+ * neighbours' masks of the planes next to the slab (cfd_set_ghost_active, once).  cfd_pair_available tells
+ * whether it can run; where it cannot, a slab gets CFD_E_STATE here, because two separate sweeps need
+ * an exchange in between that only the caller can do. */
 int cfd_sweep_pair_and_filter(cfd_handle *h);
 
 /* The same sweep (applyDiffEq_adj, src/Main.hs:202-226) in two halves, for a slab that exchanges
@@ -177,6 +182,23 @@ const char *cfd_last_error(void);
  */
 int cfd_halo_planes(cfd_handle *h, void **send_lo, void **send_hi, void **recv_lo,
                     void **recv_hi, size_t *plane_bytes);
+
+/* The same for a halo `depth` planes deep (1 or 2): send_lo = the first `depth` owned planes, send_hi =
+ * the last `depth`, recv_lo / recv_hi = the `depth` ghost planes next to the slab; bytes = depth *
+ * plane_bytes, each range contiguous.  Depth 2 serves cfd_sweep_pair_and_filter.  No counterpart in the
+ * reference (single address space). */
+int cfd_halo_planes_depth(cfd_handle *h, int depth, void **send_lo, void **send_hi, void **recv_lo,
+                          void **recv_hi, size_t *bytes);
+
+/* `active` flags (src/SolutionDomain.hs:51) of the neighbouring slabs' planes next to this slab: lo_plane
+ * = the lower neighbour's last plane, hi_plane = the upper neighbour's first plane, ny*nz bytes each, host
+ * memory; NULL on a side without a ghost plane.  Needed once, before the first
+ * cfd_sweep_pair_and_filter of a slab: the once-swept values of a ghost plane depend on which of its
+ * cells keep their velocity and dye (calcSteps_adj, src/Main.hs:180-187). */
+int cfd_set_ghost_active(cfd_handle *h, const uint8_t *lo_plane, const uint8_t *hi_plane);
+
+/* *available = 1 if cfd_sweep_pair_and_filter runs as one pass for this handle as it is now. */
+int cfd_pair_available(cfd_handle *h, int *available);
 
 /* The HIP stream (hipStream_t) all of the handle's kernels run on. */
 int cfd_stream(cfd_handle *h, void **stream);

@@ -53,6 +53,8 @@ def lib():
         L.ob_slot_ptr.restype = ctypes.POINTER(ctypes.c_double)
         L.ob_slot_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.ob_property.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.ob_active_ptr.restype = ctypes.POINTER(ctypes.c_uint8)
+        L.ob_active_ptr.argtypes = [ctypes.c_void_p]
         L.ob_superbee.restype = ctypes.c_double
         L.ob_superbee.argtypes = [ctypes.c_double, ctypes.c_double]
         L.ob_mu.restype = ctypes.c_double
@@ -114,6 +116,10 @@ class OracleB:
     def slot_view(self, slot_rel, q):
         """Writable numpy view of live field q (U V W Density Temperature Dye) of slot cmt-slot_rel."""
         return np.ctypeslib.as_array(self.L.ob_slot_ptr(self.h, slot_rel, q), shape=(self.n,))
+
+    def active_view(self):
+        """Writable numpy view of the active mask."""
+        return np.ctypeslib.as_array(self.L.ob_active_ptr(self.h), shape=(self.n,))
 
     def time(self):
         a, b = ctypes.c_int(), ctypes.c_int()

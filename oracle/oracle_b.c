@@ -487,6 +487,9 @@ void ob_property(const ob_state *s, int prop, int slot_rel, double *out) {
             }
 }
 
+/* The active mask (one byte per cell), writable: a slab harness fills in its ghost planes. */
+uint8_t *ob_active_ptr(ob_state *s) { return s->active; }
+
 /* exposed for unit tests */
 double ob_superbee(double a, double b) { return superbee(a, b); }
 double ob_mu(const ob_params *p, double t) { return mu_of(p, t); }

@@ -242,6 +242,92 @@ def test_virtual_rank_slabs_match_single_domain(world, shape, split, flags):
     assert abs(total - ref.total_density()) <= 1e-12 * abs(total)
 
 
+@pytest.mark.parametrize("world,shape", [(2, (12, 33)), (3, (15, 300)), (4, (9, 20)), (2, (4, 7)), (5, (71, 500))])
+@pytest.mark.parametrize("pair_chunk", [None, 1, 5])
+def test_virtual_rank_slabs_two_sweeps_in_one_pass(world, shape, pair_chunk, monkeypatch):
+    """Slabs whose step is one sweep behind a one-plane exchange, then the second and third sweep and the
+    filter as ONE pass behind a two-plane exchange (cfd_halo_planes_depth 2, the neighbours' masks from
+    cfd_set_ghost_active): bit-exact against the undecomposed run in every owned plane and slot.  The
+    shapes put inactive cells (the obstacle, scattered cells) on slab boundary planes, so a ghost plane's
+    once-swept values depend on the neighbour's mask."""
+    import torch
+    from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
+    if pair_chunk is not None:
+        monkeypatch.setenv("CFD_PAIR_CHUNK", str(pair_chunk))
+    nx, ny = shape
+    params, fields, active = small_case(nx, ny, 1, seed=33)
+    rng = np.random.default_rng(5)
+    off = rng.random(active.size) < 0.08              # scattered inactive cells, also on boundary planes
+    active = active.copy()
+    active[off] = 0
+    for k in (0, 1):
+        fields[k][off] = 0.0
+    ref = _gpu_graph(params, fields, active, 4)
+    ref.step(3)
+    peers = []
+    for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, nx, ny, world)):
+        p = dict(params)
+        p["nx"] = x1 - x0
+        p["flags"] = 4
+        peers.append(SlabGraph(p, f, a, rank=r, world=world, comm=LocalComm(r, peers)))
+    assert not peers[0].backend.pair_available()        # no masks yet
+    assert peers[0].use_pair()                          # hands every slab its neighbours' masks
+    assert all(g.backend.pair_available() for g in peers)
+    bounds = [nx * r // world for r in range(world + 1)]
+    for _ in range(3):
+        for g in peers:
+            g.exchange()
+        torch.cuda.synchronize()
+        for g in peers:
+            g.backend.sweep(True)
+        for g in peers:
+            g.comm.exchange(g.backend, depth=2)
+        torch.cuda.synchronize()
+        for g in peers:
+            g.backend.sweep_pair_and_filter()
+    total = 0.0
+    for r, g in enumerate(peers):
+        for rel in range(3):
+            got, want = g.read_fields(rel), ref.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(got[k], want[k][bounds[r] * ny:bounds[r + 1] * ny]), (r, rel, PROPS[k])
+        total += g.backend.total_density()
+    assert abs(total - ref.total_density()) <= 1e-12 * abs(total)
+
+
+def test_slab_pair_needs_masks_and_two_planes():
+    """A slab without its neighbours' masks, or with a single plane, cannot run the one-pass tail: the
+    entry point says so instead of running two sweeps without the exchange they need in between."""
+    from cfd_amd._capi import CfdError
+    from cfd_amd.solver import AdjGraph
+    params, fields, active = small_case(6, 9, 1, seed=2)
+    p = dict(params)
+    p.update(flags=4, ghost_lo=1, ghost_hi=0)
+    g = AdjGraph(p, fields, active)
+    assert not g.pair_available()
+    with pytest.raises(CfdError):
+        g.sweep_pair_and_filter()
+    with pytest.raises(CfdError):
+        g.set_ghost_active(None, None)                  # a mask is needed on the side that has a neighbour
+    g.set_ghost_active(np.ones(9, np.uint8), None)
+    assert g.pair_available()
+    with pytest.raises(CfdError):
+        g.halo_planes(3)
+    one = [f[:9] for f in fields]
+    p1 = dict(p)
+    p1["nx"] = 1
+    g1 = AdjGraph(p1, one, active[:9])
+    g1.set_ghost_active(np.ones(9, np.uint8), None)
+    assert not g1.pair_available()
+    with pytest.raises(CfdError):
+        g1.halo_planes(2)
+    # cfd_step on a slab takes the one-pass tail only where it is available; the ghost planes were never
+    # filled here (zeros), so only the planes three or more away from them are meaningful after a step
+    g.step(1)
+    g1.step(1)
+    assert np.all(np.isfinite(g.read_fields(0)[3][3 * 9:]))
+
+
 @pytest.mark.parametrize("kernel,chunk,variant", [(1, 32, -1), (0, 32, 0), (0, 1, 0), (0, 3, 0), (0, 32, 1),
                                                    (0, 4, 3)])
 @pytest.mark.parametrize("shape,seed,zero_v,flags", [((7, 6, 5), 1, False, 0), ((3, 3, 3), 2, True, 0),

@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _rank_main(rank, world, port, shape, q):
+def _rank_main(rank, world, port, shape, pair, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import torch.distributed as dist
@@ -38,18 +38,25 @@ def _rank_main(rank, world, port, shape, q):
         x0, x1, f, a = split_slabs(fields, active, nx, ny * nz, world)[rank]
         p = dict(params)
         p["nx"] = x1 - x0
-        g = SlabGraph(p, f, a, rank=rank, world=world, comm=DistComm(rank, world), backend_cls=OracleSlabBackend)
+        g = SlabGraph(p, f, a, rank=rank, world=world, comm=DistComm(rank, world), backend_cls=OracleSlabBackend,
+                      pair=pair)
         g.step(2)
         td = g.total_density()
         slices = [g.property_slice(k) for k in range(10)]      # collective: exchanges the ghost planes
-        q.put((rank, x0, x1, [g.read_fields(r) for r in range(3)], td, slices))
+        q.put((rank, x0, x1, [g.read_fields(r) for r in range(3)], td, slices, g.use_pair()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape", [(2, (12, 9, 1)), (3, (11, 6, 1)), (2, (8, 5, 4))])
-def test_slabs_match_single_domain(world, shape):
+# pair: the tail of a step as one pass behind a two-plane exchange (True) or as two sweeps with a one-plane
+# exchange each (False); used: what the ranks must have agreed on (a one-plane slab cannot send two planes,
+# and then no rank may use the two-plane form)
+@pytest.mark.parametrize("world,shape,pair,used", [
+    (2, (12, 9, 1), True, True), (3, (11, 6, 1), True, True), (2, (8, 5, 4), True, True),
+    (2, (12, 9, 1), False, False), (3, (11, 6, 1), False, False),
+    (3, (4, 7, 1), True, False), (2, (4, 6, 1), True, True)])
+def test_slabs_match_single_domain(world, shape, pair, used):
     sys.path.insert(0, HERE)
     from helpers import bits_equal, oracle_params, small_case
     from oracle import OracleB
@@ -60,7 +67,7 @@ def test_slabs_match_single_domain(world, shape):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, shape, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, shape, pair, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
@@ -68,7 +75,8 @@ def test_slabs_match_single_domain(world, shape):
         p.join(timeout=60)
         assert p.exitcode == 0
     plane = ny * nz
-    for rank, x0, x1, slots, td, slices in results:
+    for rank, x0, x1, slots, td, slices, paired in results:
+        assert paired == used, rank
         for k in range(10):     # output slices (Vorticity reaches into the neighbouring slabs)
             assert bits_equal(slices[k], ref.property_slice(k, (nz - 1) // 2)[x0:x1]), (rank, k)
         for rel in range(3):
