@@ -1,6 +1,6 @@
 """What the slab path costs on one GPU: a 4096 x 4096 slab with both ghost planes, stepped with whole
 sweeps and with split sweeps (interior launch, ghost-plane copy standing in for the exchange, boundary
-launches), against the undecomposed handle."""
+launches) and with the one-pass tail behind a two-plane copy, against the undecomposed handle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,6 +25,17 @@ def split(b):
     for i, st in enumerate((True, False, False)):
         sl, sh, rl, rh = b.halo_tensors()
         b.sweep_begin(st, i == 2); rl.copy_(sl); rh.copy_(sh); b.sweep_end()
+import numpy as np
+ones = np.ones(4096, np.uint8)
+def make_pair():
+    b = GpuBackend(pg, fields, active); b.set_ghost_active(ones, ones); assert b.pair_available(); return b
+def pair(b):          # what SlabGraph.step does at N > 1: split first sweep, two-plane exchange, one-pass tail
+    sl, sh, rl, rh = b.halo_tensors()
+    b.sweep_begin(True, False); rl.copy_(sl); rh.copy_(sh); b.sweep_end()
+    sl, sh, rl, rh = b.halo_tensors(2); rl.copy_(sl); rh.copy_(sh)
+    b.sweep_pair_and_filter()
 w = timed(lambda: GpuBackend(pg, fields, active), whole)
 s = timed(lambda: GpuBackend(pg, fields, active), split)
-print("ms/step: undecomposed %.4f   slab, whole sweeps %.4f   slab, split sweeps %.4f" % (plain, w, s))
+pr = timed(make_pair, pair)
+print("ms/step: undecomposed %.4f   slab, whole sweeps %.4f   slab, split sweeps %.4f   slab, split sweep + one-pass tail %.4f"
+      % (plain, w, s, pr))

@@ -27,4 +27,20 @@ torch.cuda.synchronize()
 t = torch.tensor([b.total_density()], dtype=torch.float64, device="cuda"); dist.all_reduce(t)
 print("second exchange ok:", bool(torch.equal(recv_hi.view(torch.int64), send_lo.view(torch.int64))), "all_reduce", float(t.item()),
       "finite after sweep:", bool(torch.isfinite(b.halo_tensors()[0]).all()))
+# two planes per side (the halo of the one-pass tail) and a mask plane (uint8), again to self
+import numpy as np
+b.set_ghost_active(np.ones(40, np.uint8), np.ones(40, np.uint8))
+s2_lo, s2_hi, r2_lo, r2_hi = b.halo_tensors(2)
+m_send, m_recv = b.mask_tensor(b.boundary_active()[0]), b.mask_tensor()
+ops = [dist.P2POp(dist.isend, s2_hi, 0), dist.P2POp(dist.irecv, r2_lo, 0)]
+for r in dist.batch_isend_irecv(ops): r.wait()
+ops = [dist.P2POp(dist.isend, s2_lo, 0), dist.P2POp(dist.irecv, r2_hi, 0)]
+for r in dist.batch_isend_irecv(ops): r.wait()
+ops = [dist.P2POp(dist.isend, m_send, 0), dist.P2POp(dist.irecv, m_recv, 0)]
+for r in dist.batch_isend_irecv(ops): r.wait()
+b.sweep_pair_and_filter()
+torch.cuda.synchronize()
+print("two-plane exchange ok:", bool(torch.equal(r2_lo.view(torch.int64), s2_hi.view(torch.int64))) and
+      bool(torch.equal(r2_hi.view(torch.int64), s2_lo.view(torch.int64))), r2_lo.numel(), "mask ok:", bool(torch.equal(m_send, m_recv)),
+      "pair available:", b.pair_available(), "finite after the one-pass tail:", bool(torch.isfinite(b.halo_tensors(2)[0]).all()))
 dist.barrier(); dist.destroy_process_group()

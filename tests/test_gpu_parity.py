@@ -634,6 +634,9 @@ def test_rccl_transport_on_aliased_halo_planes():
     assert out.returncode == 0, out.stderr[-2000:]
     assert "after first exchange: True" in out.stdout, out.stdout
     assert "second exchange ok: True" in out.stdout and "finite after sweep: True" in out.stdout, out.stdout
+    # the two-plane halo of the one-pass tail and a mask plane (uint8) through the same transport
+    assert "two-plane exchange ok: True" in out.stdout and "mask ok: True" in out.stdout, out.stdout
+    assert "pair available: True" in out.stdout and "finite after the one-pass tail: True" in out.stdout, out.stdout
 
 
 def test_compiled_host_prints_reference_stdout():
