@@ -854,10 +854,12 @@ def test_full_size_default_path_against_per_cell_kernel():
     g.close()
 
 
-def test_full_size_slabs_equal_undecomposed():
+@pytest.mark.parametrize("one_pass_tail", [False, True])
+def test_full_size_slabs_equal_undecomposed(one_pass_tail):
     """4096 x 4096 cut into two slabs of 2048 planes (virtual ranks, ghost planes exchanged as aliased device
-    tensors, split sweeps with the fused filter) against the undecomposed default path: after two steps the
-    slabs equal the three-launch path bit for bit, and the two-sweeps kernel of the undecomposed run too."""
+    tensors) against the undecomposed default path, bit for bit after two steps.  Slab form: three split
+    sweeps with the fused filter, or a split sweep and then the one-pass tail behind a two-plane exchange
+    (the form the multi-GPU driver takes)."""
     import torch
     from cfd_amd import cases
     from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
@@ -870,9 +872,10 @@ def test_full_size_slabs_equal_undecomposed():
     for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, FULL, FULL, 2)):
         p = dict(params)
         p["nx"] = x1 - x0
-        peers.append(SlabGraph(p, f, a, rank=r, world=2, comm=LocalComm(r, peers)))
+        peers.append(SlabGraph(p, f, a, rank=r, world=2, comm=LocalComm(r, peers), pair=one_pass_tail))
+    assert peers[0].use_pair() == one_pass_tail
     for _ in range(2):
-        for i, st in enumerate((True, False, False)):
+        for i, st in enumerate((True,) if one_pass_tail else (True, False, False)):
             for g in peers:
                 g.backend.sweep_begin(st, i == 2)
             for g in peers:
@@ -880,6 +883,12 @@ def test_full_size_slabs_equal_undecomposed():
             torch.cuda.synchronize()
             for g in peers:
                 g.backend.sweep_end()
+        if one_pass_tail:
+            for g in peers:
+                g.comm.exchange(g.backend, depth=2)
+            torch.cuda.synchronize()
+            for g in peers:
+                g.backend.sweep_pair_and_filter()
     half = FULL // 2 * FULL
     for rel in range(3):
         want = ref.read_fields(rel)
