@@ -632,7 +632,10 @@ sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
         }
         StreamA2 A;
         phaseA2s(K, Rc, hx, rn, rs, mask_of(act_j != 0), A);
-        if (first) {    // clamp-to-self on the West side (block-uniform branch, no memory operations inside)
+        if (first) {    // clamp-to-self on the West side: a real branch (the empty asm keeps it from becoming
+            // per-lane conditional moves in every row); no memory operations inside.  The filter variant is
+            // bound by memory and at its register limit, where the branch form costs scratch: left to the compiler.
+            if (!FILTER) asm volatile("");
             mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwpD = A.me[S2_DYE];
         }
         stream_west(A.q, A.coef, mwp, mwpD);
@@ -765,17 +768,20 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
         vnew[F2_DYE] = stream_finish(q1[S2_DYE], c1[S2_DYE], A.me[S2_DYE], lmsg1[3][lnc], lmsg1[3][lsc]);
         vnew[F2_RHO] = rho1;
         const int r1 = j - 1;
-        {
-            const bool above = r1 > xhi1;            // above the domain: a copy of the last defined row
+        // The three domain-end rules below depend on the row index only, so they are real (scalar) branches
+        // around plain copies: the empty asm keeps the compiler from turning them into per-lane conditional
+        // moves, which every row of every chunk would pay for.
+        if (r1 > xhi1) {                             // above the domain: a copy of the last defined row
+            asm volatile("");
 #pragma unroll
-            for (int f = 0; f < NF2; ++f) vnew[f] = above ? Vc[f] : vnew[f];
+            for (int f = 0; f < NF2; ++f) vnew[f] = Vc[f];
         }
 #pragma unroll
         for (int f = 0; f < NF2; ++f) Ve[f] = vnew[f];
-        {
-            const bool below = r1 == xlo1;          // below the domain: copies of the first defined row
+        if (r1 == xlo1) {                            // below the domain: copies of the first defined row
+            asm volatile("");
 #pragma unroll
-            for (int f = 0; f < NF2; ++f) { Vc[f] = below ? vnew[f] : Vc[f]; Vw[f] = below ? vnew[f] : Vw[f]; }
+            for (int f = 0; f < NF2; ++f) { Vc[f] = vnew[f]; Vw[f] = vnew[f]; }
         }
         // ---- stage 2: phase A of row j-2 on the once-swept values, then finish row j-3
         double hx2[NF2], rn2[NF2], rs2[NF2];
@@ -784,10 +790,9 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
         for (int f = 0; f < NF2; ++f) { rn2[f] = lraw2[f][lnc]; rs2[f] = lraw2[f][lsc]; }
         StreamA2 B;
         phaseA2s<SelPlain>(K, Vc, hx2, rn2, rs2, act2 != 0, B);
-        {   // clamp-to-self on the West side of the second sweep
-            const bool fm = j - 2 == a2first;
-            mw2[0] = fm ? B.mw[0] : mw2[0]; mw2[1] = fm ? B.mw[1] : mw2[1];
-            mw2[2] = fm ? B.mw[2] : mw2[2]; mw2D = fm ? B.me[S2_DYE] : mw2D;
+        if (j - 2 == a2first) {     // clamp-to-self on the West side of the second sweep
+            asm volatile("");
+            mw2[0] = B.mw[0]; mw2[1] = B.mw[1]; mw2[2] = B.mw[2]; mw2D = B.me[S2_DYE];
         }
         stream_west(B.q, B.coef, mw2, mw2D);
         {
@@ -1088,7 +1093,8 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
         }
         StreamA3 A;
         phaseA3s(K, Rc, h, mask_of(act_j != 0), A);
-        if (first) {    // clamp-to-self on the West side
+        if (first) {    // clamp-to-self on the West side (kept a real branch by the empty asm)
+            asm volatile("");
             mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwp[3] = A.mw[3]; mwpD = A.me[S3_DYE];
         }
         stream_west3(A.q, A.coef, mwp, mwpD);
