@@ -638,13 +638,14 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     double fE[NF2], fW[NF2];
     for (int q = 0; q < NF2; ++q) { fE[q] = c[q] + hx[q]; fW[q] = c[q] - hx[q]; }
     const double muE = mu_stream(k, fE[F2_T]), muW = mu_stream(k, fW[F2_T]);
-    const double pE = (k.R * fE[F2_T]) * fE[F2_RHO], pW = (k.R * fW[F2_T]) * fW[F2_RHO];
+    // pressure p = R (T rho): the face difference is taken on T rho and scaled by R once
+    const double pE = fE[F2_T] * fE[F2_RHO], pW = fW[F2_T] * fW[F2_RHO];
     const double mE = fE[F2_RHO] * fE[F2_U], mW = fW[F2_RHO] * fW[F2_U];
     double div[5];
     div[E2_RHO] = k.rcx * (mE - mW);
-    div[E2_U] = k.rcx * ((mE * fE[F2_U] - mW * fW[F2_U]) + (pE - pW));
+    div[E2_U] = k.rcx * fma(k.R, pE - pW, mE * fE[F2_U] - mW * fW[F2_U]);
     div[E2_V] = k.rcx * (mE * fE[F2_V] - mW * fW[F2_V]);
-    div[E2_T] = k.rcx * (k.cp * (mE * fE[F2_T] - mW * fW[F2_T]));       // cv m T + p u = (cv + R) m T
+    div[E2_T] = k.rcx * (mE * fE[F2_T] - mW * fW[F2_T]);       // cv m T + p u = (cv + R) m T: times cp below, once
     div[E2_DYE] = k.rcx * (mE * fE[F2_DYE] - mW * fW[F2_DYE]);
     const double dea = muE * fE[F2_U] - muW * fW[F2_U], deb = muE * fE[F2_V] - muW * fW[F2_V];
     // ---- y faces
@@ -654,12 +655,12 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
         fN[q] = c[q] + hy; fS[q] = c[q] - hy;
     }
     const double muN = mu_stream(k, fN[F2_T]), muS = mu_stream(k, fS[F2_T]);
-    const double pN = (k.R * fN[F2_T]) * fN[F2_RHO], pS = (k.R * fS[F2_T]) * fS[F2_RHO];
+    const double pN = fN[F2_T] * fN[F2_RHO], pS = fS[F2_T] * fS[F2_RHO];
     const double mN = fN[F2_RHO] * fN[F2_V], mS = fS[F2_RHO] * fS[F2_V];
     div[E2_RHO] = fma(k.rcy, mN - mS, div[E2_RHO]);
     div[E2_U] = fma(k.rcy, mN * fN[F2_U] - mS * fS[F2_U], div[E2_U]);
-    div[E2_V] = fma(k.rcy, (mN * fN[F2_V] - mS * fS[F2_V]) + (pN - pS), div[E2_V]);
-    div[E2_T] = fma(k.rcy, k.cp * (mN * fN[F2_T] - mS * fS[F2_T]), div[E2_T]);
+    div[E2_V] = fma(k.rcy, fma(k.R, pN - pS, mN * fN[F2_V] - mS * fS[F2_V]), div[E2_V]);
+    div[E2_T] = fma(k.rcy, mN * fN[F2_T] - mS * fS[F2_T], div[E2_T]);
     div[E2_DYE] = fma(k.rcy, mN * fN[F2_DYE] - mS * fS[F2_DYE], div[E2_DYE]);
     const double aN = muN * fN[F2_U], aS = muS * fS[F2_U];
     const double dna = aN - aS, dnb = muN * fN[F2_V] - muS * fS[F2_V];
@@ -686,7 +687,7 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     o.ms[S2_DYE] = k.kyyd * g;
     // ---- the cell's own part
     const double gU = fma(k.cUa, a, div[E2_U]), gV = fma(k.cVb, b, div[E2_V]);
-    const double gT = fma(k.kxx2, px, fma(k.kyy2, py, div[E2_T])), gD = fma(k.cDg, g, div[E2_DYE]);
+    const double gT = fma(k.kxx2, px, fma(k.kyy2, py, k.cp * div[E2_T])), gD = fma(k.cDg, g, div[E2_DYE]);
     const double rinv = fast_rcp(c[F2_RHO]);
     const double keep = S::pick(act, 1.0, 0.0);
     o.coef[S2_U] = S::pick(act & S::of(c[F2_U] != 0.0), rinv, keep);
@@ -1135,16 +1136,16 @@ CFD_HD void phaseA3s(const FastConsts& k, const double c[NF3], const double h[3]
         double fu[NF3], fl[NF3];
         for (int q = 0; q < NF3; ++q) { fu[q] = c[q] + h[d][q]; fl[q] = c[q] - h[d][q]; }
         const double muU = mu_stream(k, fu[F3_T]), muL = mu_stream(k, fl[F3_T]);
-        const double pU = (k.R * fu[F3_T]) * fu[F3_RHO], pL = (k.R * fl[F3_T]) * fl[F3_RHO];
+        const double pU = fu[F3_T] * fu[F3_RHO], pL = fl[F3_T] * fl[F3_RHO];       // p / R; scaled once below
         const double mU = fu[F3_RHO] * fu[F3_U + d], mL = fl[F3_RHO] * fl[F3_U + d];
         // flux differences across direction d (products rounded, then subtracted)
         div[E3_RHO] = fma(rc[d], mU - mL, div[E3_RHO]);
         for (int cc = 0; cc < 3; ++cc) {
             double dd = mU * fu[F3_U + cc] - mL * fl[F3_U + cc];
-            if (cc == d) dd = dd + (pU - pL);
+            if (cc == d) dd = fma(k.R, pU - pL, dd);
             div[E3_U + cc] = fma(rc[d], dd, div[E3_U + cc]);
         }
-        div[E3_T] = fma(rc[d], k.cp * (mU * fu[F3_T] - mL * fl[F3_T]), div[E3_T]);     // cv m T + p u = (cv + R) m T
+        div[E3_T] = fma(rc[d], mU * fu[F3_T] - mL * fl[F3_T], div[E3_T]);     // cv m T + p u = (cv + R) m T: times cp below, once
         div[E3_DYE] = fma(rc[d], mU * fu[F3_DYE] - mL * fl[F3_DYE], div[E3_DYE]);
         double au[3], al[3];
         for (int q = 0; q < 3; ++q) { au[q] = muU * fu[F3_U + q]; al[q] = muL * fl[F3_U + q]; dmu[d][q] = au[q] - al[q]; }
@@ -1192,7 +1193,7 @@ CFD_HD void phaseA3s(const FastConsts& k, const double c[NF3], const double h[3]
     }
     // ---- the cell's own part
     const double gU = fma(k.cUa3, a[0], div[E3_U]), gV = fma(k.cVb3, a[1], div[E3_V]), gW = fma(k.cWc3, a[2], div[E3_W]);
-    const double gT = fma(k.kxx2, pc[0], fma(k.kyy2, pc[1], fma(k.kzz2, pc[2], div[E3_T])));
+    const double gT = fma(k.kxx2, pc[0], fma(k.kyy2, pc[1], fma(k.kzz2, pc[2], k.cp * div[E3_T])));
     const double gD = fma(k.cDg3, g, div[E3_DYE]);
     const double rinv = fast_rcp(c[F3_RHO]);
     const double keep = select(act, 1.0, 0.0);
