@@ -51,6 +51,11 @@ foreign import ccall safe "cfd_sweep_pair_and_filter" c_sweepPairAndFilter :: Pt
 foreign import ccall safe "cfd_property_slice" c_propertySlice :: Ptr CfdHandle -> CInt -> CInt -> CInt -> Ptr Double -> IO CInt
 foreign import ccall safe "cfd_sweep_begin" c_sweepBegin :: Ptr CfdHandle -> CInt -> CInt -> IO CInt
 foreign import ccall safe "cfd_sweep_end" c_sweepEnd :: Ptr CfdHandle -> IO CInt
+-- slabs (several GPUs): halo ranges one or two planes deep, the neighbours' masks, availability of the one-pass tail
+foreign import ccall safe "cfd_halo_planes_depth"
+    c_haloPlanesDepth :: Ptr CfdHandle -> CInt -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr CSize -> IO CInt
+foreign import ccall safe "cfd_set_ghost_active" c_setGhostActive :: Ptr CfdHandle -> Ptr Word8 -> Ptr Word8 -> IO CInt
+foreign import ccall safe "cfd_pair_available" c_pairAvailable :: Ptr CfdHandle -> Ptr CInt -> IO CInt
 foreign import ccall safe "cfd_total_density" c_density :: Ptr CfdHandle -> Ptr Double -> IO CInt
 foreign import ccall safe "cfd_read_fields" c_read :: Ptr CfdHandle -> CInt -> Ptr (Ptr Double) -> IO CInt
 foreign import ccall safe "cfd_time" c_time :: Ptr CfdHandle -> Ptr CInt -> Ptr CInt -> IO CInt
