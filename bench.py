@@ -121,11 +121,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     from cfd_amd import cases
-    from cfd_amd.slab import SlabGraph
+    from cfd_amd.slab import SlabGraph, init_rccl
+    if world > 1:
+        init_rccl(torch.device("cuda", local_rank))     # rank, world size and rendezvous from the environment
 
     global_nx = a.nx if a.strong else a.nx * world
     if a.strong:

@@ -1740,9 +1740,14 @@ int cfd_sweep_pair_and_filter(cfd_handle* h) {
 }
 
 int cfd_sweep_begin(cfd_handle* h, int step_time, int with_filter) {
+    return cfd_sweep_begin_depth(h, step_time, with_filter, 1);
+}
+
+int cfd_sweep_begin_depth(cfd_handle* h, int step_time, int with_filter, int edge_planes) {
     if (!h) return fail(CFD_E_ARG, "cfd_sweep_begin: null handle");
     if (h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_begin: a split sweep is already open");
     if (step_time && with_filter) return fail(CFD_E_ARG, "cfd_sweep_begin: the filter follows a sweep that does not advance time");
+    if (edge_planes < 1) return fail(CFD_E_ARG, "cfd_sweep_begin_depth: edge_planes must be >= 1");
     HIP_TRY(hipSetDevice(h->device));
     auto& q = h->pend;
     q.step_time = step_time != 0;
@@ -1757,9 +1762,10 @@ int cfd_sweep_begin(cfd_handle* h, int step_time, int with_filter) {
         q.fpp = slot_base(h, tc);
         q.fprev = slot_base(h, tb);
     }
-    // planes 1 .. nx-2 read owned planes only; plane 0 / nx-1 also read a ghost plane if there is one
-    q.x0 = h->p.ghost_lo ? 1 : 0;
-    q.x1 = h->p.ghost_hi ? h->p.nx - 1 : h->p.nx;
+    // planes 1 .. nx-2 read owned planes only; plane 0 / nx-1 also read a ghost plane if there is one.
+    // edge_planes > 1 leaves that many planes on every side with a neighbour to cfd_sweep_end.
+    q.x0 = h->p.ghost_lo ? (edge_planes < h->p.nx ? edge_planes : h->p.nx) : 0;
+    q.x1 = h->p.ghost_hi ? h->p.nx - edge_planes : h->p.nx;
     if (q.x1 < q.x0) q.x1 = q.x0;
     int rc = launch_sweep(h, q.src, q.dst, q.fpp, q.fprev, &q.fused, q.x0, q.x1);
     if (rc) return rc;
@@ -1769,12 +1775,22 @@ int cfd_sweep_begin(cfd_handle* h, int step_time, int with_filter) {
 
 int cfd_sweep_end(cfd_handle* h) {
     if (!h) return fail(CFD_E_ARG, "cfd_sweep_end: null handle");
+    return cfd_sweep_end_on(h, (void*)h->stream);
+}
+
+int cfd_sweep_end_on(cfd_handle* h, void* stream) {
+    if (!h) return fail(CFD_E_ARG, "cfd_sweep_end: null handle");
     if (!h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_end: no split sweep is open");
     HIP_TRY(hipSetDevice(h->device));
     auto& q = h->pend;
+    if (q.with_filter && (hipStream_t)stream != h->stream)
+        return fail(CFD_E_ARG, "cfd_sweep_end_on: a sweep with the filter completes on the handle's own stream");
+    // the edge launches go to the stream named by the caller; the handle's own stream is untouched
+    const hipStream_t own = h->stream;
+    h->stream = (hipStream_t)stream;
     int rc = launch_sweep(h, q.src, q.dst, q.fpp, q.fprev, &q.fused, 0, q.x0);
-    if (rc) return rc;
-    rc = launch_sweep(h, q.src, q.dst, q.fpp, q.fprev, &q.fused, q.x1, h->p.nx);
+    if (!rc) rc = launch_sweep(h, q.src, q.dst, q.fpp, q.fprev, &q.fused, q.x1, h->p.nx);
+    h->stream = own;
     if (rc) return rc;
     q.open = false;
     if (q.step_time) {

@@ -21,9 +21,24 @@ The transport is pluggable so that the orchestration can be exercised without GP
              "gloo" in the CPU tests)
   LocalComm  several slabs inside one process (virtual ranks), planes copied directly
 """
+import os
+
 import numpy as np
 
 from .solver import AdjGraph
+
+
+def init_rccl(device, high_priority=True, **kw):
+    """Process group on the nccl (= RCCL) backend bound to `device` (a torch.device).  high_priority: the
+    group's transfers run on a stream of torch's high-priority pool.  Streams of the normal pool can share a
+    hardware queue with the default stream, on which the sweeps run; an exchange queued behind a sweep in
+    the same hardware queue cannot run beside it, whatever the stream order allows."""
+    import torch.distributed as dist
+    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=bool(high_priority))
+    dist.init_process_group("nccl", device_id=device, pg_options=opts, **kw)
+
+
+_SIDE_STREAMS = {}      # device index -> the process's side stream on that device
 
 
 class _DeviceSpan:
@@ -48,6 +63,7 @@ class GpuBackend:
         # run on torch's current stream so that torch.distributed's stream ordering covers the kernels
         self.graph.set_stream(torch.cuda.current_stream().cuda_stream)
         self._cache = {}
+        self._side = self._main = None
 
     def halo_tensors(self, depth=1):
         ptrs, nbytes = self.graph.halo_planes(depth)
@@ -76,6 +92,33 @@ class GpuBackend:
 
     def halo_commit(self, depth=1):
         """Received planes land directly in the time slot; nothing to unpack."""
+
+    # A second stream for the boundary work of a step (edge planes of the first sweep and both exchanges),
+    # so that it runs beside the interior launch on the main stream instead of behind it.
+    def fork(self):
+        """Orders the side stream after everything queued on the main stream so far."""
+        torch = self._torch
+        if self._side is None:
+            self._main = torch.cuda.current_stream()
+            # one side stream per device, shared by every slab of the process (normally there is one slab); high
+            # priority, so that its few blocks are dispatched ahead of the interior's
+            dev = torch.cuda.current_device()
+            if dev not in _SIDE_STREAMS:
+                _SIDE_STREAMS[dev] = torch.cuda.Stream(priority=int(os.environ.get("CFD_SIDE_PRIORITY", "-1")))
+            self._side = _SIDE_STREAMS[dev]
+        self._side.wait_stream(self._main)
+
+    def side(self):
+        """Context: torch work (and the process group's stream ordering) inside it refers to the side stream."""
+        return self._torch.cuda.stream(self._side)
+
+    def sweep_end_side(self):
+        """The edge planes of the open split sweep, launched on the side stream."""
+        self.graph.sweep_end(self._side.cuda_stream)
+
+    def join(self):
+        """Orders the main stream after the side stream."""
+        self._main.wait_stream(self._side)
 
     def scalar_tensor(self, v):
         return self._torch.tensor([v], dtype=self._torch.float64, device="cuda")
@@ -203,9 +246,11 @@ class LocalComm:
 class SlabGraph:
     """One rank's slab.  `fields` / `active` hold this rank's owned planes only."""
 
-    def __init__(self, params, fields, active, rank=0, world=1, comm=None, backend_cls=GpuBackend, pair=True):
+    def __init__(self, params, fields, active, rank=0, world=1, comm=None, backend_cls=GpuBackend, pair=True,
+                 overlap=True):
         """pair=False keeps the three-sweeps-per-step form (one-plane halos only) even where the one-pass
-        tail is available; every rank must pass the same value."""
+        tail is available; every rank must pass the same value.  overlap=False keeps the two-plane exchange
+        of the one-pass tail on the main stream, behind the whole first sweep."""
         p = dict(params)
         p["ghost_lo"] = 1 if rank > 0 else 0
         p["ghost_hi"] = 1 if rank < world - 1 else 0
@@ -215,6 +260,7 @@ class SlabGraph:
         self.comm = comm if comm is not None else DistComm(rank, world)
         self._masks_set = False
         self._use_pair = None if pair else False
+        self.overlap = overlap
 
     def set_ghost_masks(self):
         """Hands the backend the neighbouring slabs' masks of the planes next to this slab (once; a
@@ -249,6 +295,25 @@ class SlabGraph:
         self.comm.exchange_wait(self.backend, reqs)
         self.backend.sweep_end()                            # first / last plane, slot rotation
 
+    def _step_overlapped(self):
+        """One step with both exchanges beside the first sweep's interior launch: the one-plane exchange,
+        the two planes next to each neighbour and the two-plane exchange of their results run on a side
+        stream while the main stream computes every other plane; the one-pass tail follows both."""
+        b, c = self.backend, self.comm
+        # Both the transport and the side stream are ordered after the previous step on the main stream.  The two
+        # markers this puts in front of the interior launch hold it back just long enough for the first exchange
+        # to be dispatched beside it: measured on MI355X, an exchange dispatched a few microseconds AFTER the
+        # interior launch finds no free compute unit until that launch ends.
+        reqs = c.exchange_start(b)
+        b.fork()
+        b.sweep_begin(True, False, edge=2)          # main stream: planes two or more away from a ghost plane
+        with b.side():
+            c.exchange_wait(b, reqs)                # side stream waits for the ghost planes
+            b.sweep_end_side()                      # two planes per side; the slot advances
+            c.exchange(b, depth=2)                  # their results, two planes per side, and the wait for them
+        b.join()
+        b.sweep_pair_and_filter()
+
     def sweep(self, step_time):
         self._sweep(step_time, False)
         return self
@@ -262,7 +327,11 @@ class SlabGraph:
             self.backend.step(nsteps)       # undecomposed: the library's own step (second and third sweep in one pass)
             return self
         pair = self.use_pair()
+        overlap = pair and self.overlap and hasattr(self.backend, "fork")
         for _ in range(nsteps):
+            if overlap:
+                self._step_overlapped()
+                continue
             self._sweep(True, False)
             if pair:
                 self.comm.exchange(self.backend, depth=2)       # two planes per side: both remaining sweeps

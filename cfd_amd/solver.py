@@ -129,14 +129,19 @@ class AdjGraph:
         check(self._lib.cfd_sweep_pair_and_filter(self._h))
         return self
 
-    def sweep_begin(self, step_time, with_filter=False):
-        """First half of a split sweep: the planes that need no ghost plane (see include/cfd_hip.h)."""
-        check(self._lib.cfd_sweep_begin(self._h, 1 if step_time else 0, 1 if with_filter else 0))
+    def sweep_begin(self, step_time, with_filter=False, edge=1):
+        """First half of a split sweep: the planes that are `edge` or more planes away from a ghost plane
+        (edge = 1: all that need no ghost plane; see include/cfd_hip.h)."""
+        check(self._lib.cfd_sweep_begin_depth(self._h, 1 if step_time else 0, 1 if with_filter else 0, int(edge)))
         return self
 
-    def sweep_end(self):
-        """Second half of a split sweep: the planes next to a ghost plane, then the slot rotation."""
-        check(self._lib.cfd_sweep_end(self._h))
+    def sweep_end(self, raw_stream=None):
+        """Second half of a split sweep: the planes left out by sweep_begin, then the slot rotation.
+        raw_stream: launch them on that HIP stream (hipStream_t value) instead of the graph's own."""
+        if raw_stream is None:
+            check(self._lib.cfd_sweep_end(self._h))
+        else:
+            check(self._lib.cfd_sweep_end_on(self._h, ctypes.c_void_p(int(raw_stream))))
         return self
 
     def total_density(self):

@@ -141,6 +141,19 @@ int cfd_sweep_pair_and_filter(cfd_handle *h);
 int cfd_sweep_begin(cfd_handle *h, int step_time, int with_filter);
 int cfd_sweep_end(cfd_handle *h);
 
+/* The split sweep with a deeper edge and the edge on another stream (no counterpart in the reference;
+ * for slabs that hide BOTH exchanges of a step behind the first sweep's interior planes).
+ * cfd_sweep_begin_depth leaves edge_planes (>= 1) planes on every side that has a neighbour to the
+ * second half; cfd_sweep_begin is the case edge_planes == 1.  cfd_sweep_end_on launches that second
+ * half on `stream` (a hipStream_t of the handle's device) instead of the handle's own stream and
+ * completes the sweep as cfd_sweep_end does; the caller orders `stream` after the arrival of the ghost
+ * planes and after whatever wrote the source slot, and orders later work after `stream`.  With
+ * edge_planes == 2 the planes cfd_halo_planes_depth(h, 2, ...) names are complete as soon as `stream`
+ * has run, while the interior launch may still be running on the handle's stream.  A sweep begun
+ * with with_filter != 0 completes on the handle's own stream only (CFD_E_ARG otherwise). */
+int cfd_sweep_begin_depth(cfd_handle *h, int step_time, int with_filter, int edge_planes);
+int cfd_sweep_end_on(cfd_handle *h, void *stream);
+
 /* totalDensity (src/Main.hs:269-270): sum of Density over slot currModTime-1 (owned planes).
  * The reference folds sequentially; this is a tree reduction, so the last bits may differ. */
 int cfd_total_density(cfd_handle *h, double *out);

@@ -9,7 +9,8 @@ from helpers import small_case
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from cfd_amd.slab import init_rccl
+init_rccl(torch.device("cuda", 0), rank=0, world_size=1)       # as bench.py sets it up
 params, fields, active = small_case(12, 40, 1, 5)
 p = dict(params); p["ghost_lo"] = 1; p["ghost_hi"] = 1; p["flags"] = 4
 b = GpuBackend(p, fields, active)
@@ -43,4 +44,21 @@ torch.cuda.synchronize()
 print("two-plane exchange ok:", bool(torch.equal(r2_lo.view(torch.int64), s2_hi.view(torch.int64))) and
       bool(torch.equal(r2_hi.view(torch.int64), s2_lo.view(torch.int64))), r2_lo.numel(), "mask ok:", bool(torch.equal(m_send, m_recv)),
       "pair available:", b.pair_available(), "finite after the one-pass tail:", bool(torch.isfinite(b.halo_tensors(2)[0]).all()))
+# SlabGraph.step's N > 1 forms with the rank as its own neighbour on both sides (tests/self_comm.py): both
+# exchanges beside the interior planes of the first sweep (side stream, cfd_sweep_begin_depth / cfd_sweep_end_on)
+# against the two-plane exchange behind the whole first sweep, and against three sweeps with one-plane exchanges
+from cfd_amd.slab import SlabGraph
+from self_comm import SelfComm
+from helpers import bits_equal
+params, fields, active = small_case(70, 300, 1, 9)
+p = dict(params); p["flags"] = 4
+runs = []
+for kw in (dict(overlap=True), dict(overlap=False), dict(pair=False)):
+    g = SlabGraph(p, fields, active, rank=1, world=3, comm=SelfComm(), **kw)
+    g.step(4)
+    torch.cuda.synchronize()
+    runs.append(([g.read_fields(r) for r in range(3)], g.use_pair()))
+    g.close()
+same = all(bits_equal(runs[0][0][r][k], runs[i][0][r][k]) for i in (1, 2) for r in range(3) for k in range(7))
+print("overlapped step ok:", same, "forms:", [u for _, u in runs], "finite:", bool(np.isfinite(runs[0][0][0][3]).all()))
 dist.barrier(); dist.destroy_process_group()

@@ -107,8 +107,22 @@ class OracleSlabBackend:
 
     # split sweep: the oracle has no partial sweep, so the whole sweep runs at the end -- by which
     # time the orchestration under test must have delivered the ghost planes
-    def sweep_begin(self, step_time, with_filter=False):
+    def sweep_begin(self, step_time, with_filter=False, edge=1):
         self._open = (step_time, with_filter)
+
+    # the side stream of the GPU backend: on the CPU everything is in program order already
+    def fork(self):
+        pass
+
+    def side(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def sweep_end_side(self):
+        self.sweep_end()
+
+    def join(self):
+        pass
 
     def sweep_end(self):
         step_time, with_filter = self._open

@@ -295,6 +295,67 @@ def test_virtual_rank_slabs_two_sweeps_in_one_pass(world, shape, pair_chunk, mon
     assert abs(total - ref.total_density()) <= 1e-12 * abs(total)
 
 
+@pytest.mark.parametrize("world,shape", [(2, (12, 33)), (3, (15, 300)), (4, (9, 20)), (2, (4, 7)), (3, (7, 50)), (5, (71, 500))])
+def test_virtual_rank_slabs_edge_planes_on_a_side_stream(world, shape):
+    """The first sweep of a step split two planes deep (cfd_sweep_begin_depth) with the edge planes launched on
+    another stream (cfd_sweep_end_on) beside the interior launch, then the one-pass tail: bit-exact against the
+    undecomposed run.  Slabs of 2, 3 and 4 planes have an empty or one-plane interior."""
+    import torch
+    from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
+    nx, ny = shape
+    params, fields, active = small_case(nx, ny, 1, seed=34)
+    ref = _gpu_graph(params, fields, active, 4)
+    ref.step(3)
+    peers = []
+    for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, nx, ny, world)):
+        p = dict(params)
+        p["nx"] = x1 - x0
+        p["flags"] = 4
+        peers.append(SlabGraph(p, f, a, rank=r, world=world, comm=LocalComm(r, peers)))
+    assert peers[0].use_pair()
+    bounds = [nx * r // world for r in range(world + 1)]
+    for _ in range(3):
+        for g in peers:
+            g.exchange()
+        torch.cuda.synchronize()
+        for g in peers:
+            g.backend.fork()
+            g.backend.sweep_begin(True, False, edge=2)
+        for g in peers:
+            g.backend.sweep_end_side()
+        torch.cuda.synchronize()
+        for g in peers:
+            g.comm.exchange(g.backend, depth=2)
+        torch.cuda.synchronize()
+        for g in peers:
+            g.backend.join()
+            g.backend.sweep_pair_and_filter()
+    for r, g in enumerate(peers):
+        for rel in range(3):
+            got, want = g.read_fields(rel), ref.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(got[k], want[k][bounds[r] * ny:bounds[r + 1] * ny]), (r, rel, PROPS[k])
+
+
+def test_split_sweep_with_filter_stays_on_the_own_stream():
+    """cfd_sweep_end_on refuses another stream for a sweep begun with the filter (an unfused filter launch would
+    not be ordered after it)."""
+    import torch
+    from cfd_amd._capi import CfdError
+    from cfd_amd.solver import AdjGraph
+    params, fields, active = small_case(8, 9, 1, seed=2)
+    p = dict(params)
+    p.update(flags=4, ghost_lo=1, ghost_hi=1)
+    g = AdjGraph(p, fields, active)
+    side = torch.cuda.Stream()
+    g.sweep_begin(False, True)
+    with pytest.raises(CfdError):
+        g.sweep_end(side.cuda_stream)
+    g.sweep_end()
+    g.sync()
+    g.close()
+
+
 def test_slab_pair_needs_masks_and_two_planes():
     """A slab without its neighbours' masks, or with a single plane, cannot run the one-pass tail: the
     entry point says so instead of running two sweeps without the exchange they need in between."""
@@ -637,6 +698,8 @@ def test_rccl_transport_on_aliased_halo_planes():
     # the two-plane halo of the one-pass tail and a mask plane (uint8) through the same transport
     assert "two-plane exchange ok: True" in out.stdout and "mask ok: True" in out.stdout, out.stdout
     assert "pair available: True" in out.stdout and "finite after the one-pass tail: True" in out.stdout, out.stdout
+    # SlabGraph.step's three N > 1 forms over the same transport (the rank as its own neighbour) agree bit for bit
+    assert "overlapped step ok: True forms: [True, True, False] finite: True" in out.stdout, out.stdout
 
 
 def test_compiled_host_prints_reference_stdout():
