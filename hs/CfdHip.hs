@@ -51,6 +51,9 @@ foreign import ccall safe "cfd_sweep_pair_and_filter" c_sweepPairAndFilter :: Pt
 foreign import ccall safe "cfd_property_slice" c_propertySlice :: Ptr CfdHandle -> CInt -> CInt -> CInt -> Ptr Double -> IO CInt
 foreign import ccall safe "cfd_sweep_begin" c_sweepBegin :: Ptr CfdHandle -> CInt -> CInt -> IO CInt
 foreign import ccall safe "cfd_sweep_end" c_sweepEnd :: Ptr CfdHandle -> IO CInt
+-- the split sweep with an edge of several planes, and the edge launched on another stream
+foreign import ccall safe "cfd_sweep_begin_depth" c_sweepBeginDepth :: Ptr CfdHandle -> CInt -> CInt -> CInt -> IO CInt
+foreign import ccall safe "cfd_sweep_end_on" c_sweepEndOn :: Ptr CfdHandle -> Ptr () -> IO CInt
 -- slabs (several GPUs): halo ranges one or two planes deep, the neighbours' masks, availability of the one-pass tail
 foreign import ccall safe "cfd_halo_planes_depth"
     c_haloPlanesDepth :: Ptr CfdHandle -> CInt -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr CSize -> IO CInt
