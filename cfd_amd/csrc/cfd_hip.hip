@@ -74,6 +74,8 @@ struct cfd_handle {
     SweepConsts K;
     FastConsts KF;
     int chunk;              // x-planes per block of the tiled sweep
+    bool chunk_auto;        // default 2-D streaming kernel: chunk length chosen per launch (stream_chunk)
+    int cus;                // compute units of the device
     int variant;            // tiled-kernel launch shape (tuning knob)
     bool march3_ok;         // a 3-D x-plane fits 32-bit byte offsets (tiled 3-D kernel usable)
     bool pair_enabled;      // cfd_step runs its second and third sweep in one pass (env CFD_PAIR, default on)
@@ -336,6 +338,18 @@ __device__ __forceinline__ unsigned xcd_contiguous_id(unsigned orig, unsigned nw
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + orig / 8u;
 }
 
+// How the tiles of a 2-D tiled launch map to blocks.  A row of ny columns is cut into tiles of wcols; every
+// tile but possibly the last is full.  A last tile narrow enough to fit one wave together with its halo lanes
+// (nlast + halo <= 64) does not get a block of its own per chunk of x-planes: the nt / 64 waves of one block
+// take that tile for nt / 64 consecutive chunks ("packed" blocks; each wave is a complete, independent tile).
+// Linear block ids: nfull * nchunk ordinary blocks (tile fastest), then npacked packed ones.
+struct TilePlan { int nfull, npacked, pack; };
+__host__ __device__ inline TilePlan tile_plan(int ny, int wcols, int nt, int halo, int nchunk) {
+    const int ntile = (ny + wcols - 1) / wcols, nlast = ny - (ntile - 1) * wcols, pack = nt / 64;
+    const bool p = pack > 1 && nlast + halo <= 64;
+    return TilePlan{p ? ntile - 1 : ntile, p ? (nchunk + pack - 1) / pack : 0, pack};
+}
+
 // Buffer-resource addressing: one 128-bit descriptor per x-plane (built from block-uniform values,
 // so it lives in scalar registers), a per-lane 32-bit byte offset for the column, and a scalar
 // byte offset for the field.  No per-lane 64-bit address arithmetic; an out-of-range per-lane
@@ -396,22 +410,27 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     const unsigned wg = xcd_contiguous_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     const int bx = (int)(wg % gridDim.x), by = (int)(wg / gridDim.x);
     const int ytile = bx * WCOLS;
-    const int y = t < WCOLS ? ytile + t : (t == WCOLS ? ytile + WCOLS : ytile - 1);
+    // nv: the tile's own columns that exist (fewer than WCOLS in the last tile of a row); the two halo lanes
+    // follow them directly, and waves that hold no used lane leave at once (a barrier counts only the waves
+    // of the block that have not ended), so a narrow last tile costs one wave instead of NT / 64.
+    const int nv = ny - ytile < WCOLS ? ny - ytile : WCOLS;
+    if ((int)(__builtin_amdgcn_readfirstlane(t) & ~63) > nv + 1) return;
+    const int y = t < nv ? ytile + t : (t == nv ? ytile + nv : ytile - 1);
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
     const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
     auto lane_of = [=](int c) {         // lane that holds column c; outside the tile: this lane (own value)
         const int r = c - ytile;
-        return r >= 0 && r < WCOLS ? r : (r == WCOLS ? WCOLS : (r == -1 ? WCOLS + 1 : t));
+        return r >= 0 && r < nv ? r : (r == nv ? nv : (r == -1 ? nv + 1 : t));
     };
     const int lnc = lane_of(yn), lsc = lane_of(ys);
-    const bool writer = t < WCOLS && y < ny;
+    const bool writer = t < nv;
     const int xs = x0 + by * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
     const int j1 = xe < xhi ? xe : xhi;
     const long plane5 = (long)NF2 * ny;
     const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
-    const unsigned vc = t <= WCOLS + 1 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // lanes past the tile load nothing
+    const unsigned vc = t <= nv + 1 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // lanes past the tile load nothing
     const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
     auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
     auto load_row = [&](int x, unsigned voff, double v[NF2]) {
@@ -540,19 +559,36 @@ sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     // multiple of 16 every wave's store covers whole, aligned 128-byte lines (a tile that starts one
     // lane late halves the store bandwidth); lane WCOLS holds the column above the tile, lane
     // WCOLS+1 the column below it, lanes past that idle.
-    const unsigned wg = swizzle ? xcd_contiguous_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y)
-                                       : blockIdx.x + gridDim.x * blockIdx.y;
-    const int bx = (int)(wg % gridDim.x), by = (int)(wg / gridDim.x);
+    const int nchunk = (nx - x0 + ch - 1) / ch;
+    const TilePlan tp = tile_plan(ny, WCOLS, NT, 2, nchunk);
+    const unsigned wg = swizzle ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int wave0 = (int)(__builtin_amdgcn_readfirstlane(t) & ~63);      // first lane of this wave (scalar)
+    int bx, by, lb = 0;
+    if (wg < (unsigned)(tp.nfull * nchunk)) {
+        bx = (int)(wg % (unsigned)tp.nfull);
+        by = (int)(wg / (unsigned)tp.nfull);
+    } else {        // packed block: this wave is the row's narrow last tile for one chunk, lanes lb .. lb + 63
+        bx = tp.nfull;
+        by = (int)(wg - (unsigned)(tp.nfull * nchunk)) * tp.pack + (wave0 >> 6);
+        lb = wave0;
+        if (by >= nchunk) return;
+    }
+    const int tl = t - lb;      // lane within the tile
     const int ytile = bx * WCOLS;
-    const int y = t < WCOLS ? ytile + t : (t == WCOLS ? ytile + WCOLS : ytile - 1);
+    // nv: the tile's own columns that exist (fewer than WCOLS in the last tile of a row); the two halo lanes
+    // follow them directly, and waves that hold no used lane leave at once (a barrier counts only the waves
+    // of the block that have not ended).
+    const int nv = ny - ytile < WCOLS ? ny - ytile : WCOLS;
+    if (wave0 - lb > nv + 1) return;
+    const int y = tl < nv ? ytile + tl : (tl == nv ? ytile + nv : ytile - 1);
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
     const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
     auto lane_of = [=](int c) {         // lane that holds column c; outside the tile: this lane (own value)
         const int r = c - ytile;
-        return r >= 0 && r < WCOLS ? r : (r == WCOLS ? WCOLS : (r == -1 ? WCOLS + 1 : t));
+        return lb + (r >= 0 && r < nv ? r : (r == nv ? nv : (r == -1 ? nv + 1 : tl)));
     };
     const int lnc = lane_of(yn), lsc = lane_of(ys);
-    const bool writer = t < WCOLS && y < ny;
+    const bool writer = tl < nv;
     const int xs = x0 + by * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const int j0 = xs - 1 > xlo ? xs - 1 : xlo;
@@ -563,7 +599,7 @@ sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     const int j1 = xe;
     const long plane5 = (long)NF2 * ny;
     const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
-    const unsigned vc = t <= WCOLS + 1 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // lanes past the tile load nothing
+    const unsigned vc = tl <= nv + 1 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // lanes past the tile load nothing
     const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
     auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
     auto load_row = [&](int x, double v[NF2]) {
@@ -698,31 +734,47 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     static_assert(WCOLS + 4 <= NT, "block too small for the tile and its two halo columns per side");
     __shared__ double lraw1[NF2][NT], lmsg1[6][NT], lraw2[NF2][NT], lmsg2[6][NT];
     const int t = threadIdx.x;
-    const unsigned wg = xcd_contiguous_id(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-    const int bx = (int)(wg % gridDim.x), by = (int)(wg / gridDim.x);
+    const int nchunk = (nx - x0 + ch - 1) / ch;
+    const TilePlan tp = tile_plan(ny, WCOLS, NT, 4, nchunk);
+    const unsigned wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int wave0 = (int)(__builtin_amdgcn_readfirstlane(t) & ~63);      // first lane of this wave (scalar)
+    int bx, by, lb = 0;
+    if (wg < (unsigned)(tp.nfull * nchunk)) {
+        bx = (int)(wg % (unsigned)tp.nfull);
+        by = (int)(wg / (unsigned)tp.nfull);
+    } else {        // packed block: this wave is the row's narrow last tile for one chunk (see tile_plan)
+        bx = tp.nfull;
+        by = (int)(wg - (unsigned)(tp.nfull * nchunk)) * tp.pack + (wave0 >> 6);
+        lb = wave0;
+        if (by >= nchunk) return;
+    }
+    const int tl = t - lb;      // lane within the tile
     const int ytile = bx * WCOLS;
+    // nv: the tile's own columns that exist; the four halo lanes follow them, and waves without a used lane
+    // leave at once (see sweep2d_stream)
+    const int nv = ny - ytile < WCOLS ? ny - ytile : WCOLS;
+    if (wave0 - lb > nv + 3) return;
     // lanes: own columns, then +1 above, -1 below, +2 above, -2 below
-    const int y = t < WCOLS ? ytile + t
-                            : (t == WCOLS ? ytile + WCOLS
-                                          : (t == WCOLS + 1 ? ytile - 1 : (t == WCOLS + 2 ? ytile + WCOLS + 1 : ytile - 2)));
+    const int y = tl < nv ? ytile + tl
+                          : (tl == nv ? ytile + nv : (tl == nv + 1 ? ytile - 1 : (tl == nv + 2 ? ytile + nv + 1 : ytile - 2)));
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
     const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
     auto lane_of = [=](int c) {         // lane that holds column c; outside the tile and its halo: this lane
         const int r = c - ytile;
-        if (r >= 0 && r < WCOLS) return r;
-        if (r == WCOLS) return WCOLS;
-        if (r == -1) return WCOLS + 1;
-        if (r == WCOLS + 1) return WCOLS + 2;
-        if (r == -2) return WCOLS + 3;
+        if (r >= 0 && r < nv) return lb + r;
+        if (r == nv) return lb + nv;
+        if (r == -1) return lb + nv + 1;
+        if (r == nv + 1) return lb + nv + 2;
+        if (r == -2) return lb + nv + 3;
         return t;
     };
     const int lnc = lane_of(yn), lsc = lane_of(ys);
-    const bool writer = t < WCOLS && y < ny;
+    const bool writer = tl < nv;
     const int xs = x0 + by * ch;
     const int xe = xs + ch < nx ? xs + ch : nx;
     const long plane5 = (long)NF2 * ny;
     const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
-    const unsigned vc = t <= WCOLS + 3 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // idle lanes load nothing
+    const unsigned vc = tl <= nv + 3 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // idle lanes load nothing
     const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;
     auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
     auto load_row = [&](int x, double v[NF2]) {
@@ -1305,6 +1357,25 @@ static size_t march3_lds_bytes(int nt) {
 }
 
 // x0, x1: the range of owned x-planes to compute (x1 < 0: all of them).
+// x-planes per block for the default 2-D streaming launch (256 threads, 240 columns) over nplanes planes.
+// Three of its blocks fit a compute unit and every block of a launch takes the same time, so a launch runs in
+// ceil(blocks / (3 * CUs)) rounds of (chunk + 2) rows each (two rows per chunk are computed for the neighbours
+// only); measured launch times follow that product.  Chunks between 24 and 40 planes: longer ones finish in
+// fewer rounds but leave the last round's tail unbalanced.
+static int stream_chunk(const cfd_handle* h, int nplanes) {
+    const long slots = 3L * h->cus;
+    int best = 32;
+    long best_cost = -1;
+    for (int ch = 24; ch <= 40; ++ch) {
+        const int nchunk = (nplanes + ch - 1) / ch;
+        const TilePlan tp = tile_plan(h->p.ny, 240, 256, 2, nchunk);
+        const long blocks = (long)tp.nfull * nchunk + tp.npacked;
+        const long cost = ((blocks + slots - 1) / slots) * (ch + 2);
+        if (best_cost < 0 || cost < best_cost) { best = ch; best_cost = cost; }
+    }
+    return best;
+}
+
 static int launch_sweep(cfd_handle* h, const double* src, double* dst, const double* fpp = nullptr,
                         double* fprev = nullptr, bool* did_fuse = nullptr, int x0 = 0, int x1 = -1) {
     bool fused = false;
@@ -1338,7 +1409,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
             hipExtLaunchKernelGGL(sweep2d_simple<MathStrict2>, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst,
                                   act, x0, x1, p.ny, xlo, xhi);
     } else if (h->two_d) {
-        const int ch = h->chunk;
+        const int ch = (h->chunk_auto && fast && h->variant < 0) ? stream_chunk(h, x1 - x0) : h->chunk;
 #define LAUNCH_MARCH2(M, KK, NT, MINW) LAUNCH_MARCH2W(M, KK, NT, MINW, (NT - 2))
 #define LAUNCH_MARCH2W(M, KK, NT, MINW, WC)                                                         \
     do {                                                                                           \
@@ -1357,7 +1428,9 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
 #define LAUNCH_STREAM(NT, MINW, WC) LAUNCH_STREAM_RD(NT, MINW, WC, 3)
 #define LAUNCH_STREAM_RD(NT, MINW, WC, RDV)                                                         \
     do {                                                                                           \
-        dim3 block(NT), grid((p.ny + WC - 1) / WC, (x1 - x0 + ch - 1) / ch);                          \
+        const int nchunk = (x1 - x0 + ch - 1) / ch;                                                \
+        const TilePlan tp = tile_plan(p.ny, WC, NT, 2, nchunk);                                    \
+        dim3 block(NT), grid(tp.nfull * nchunk + tp.npacked);                                      \
         if (fpp)                                                                                   \
             hipExtLaunchKernelGGL((sweep2d_stream<NT, MINW, true, RDV, WC>), grid, block, 0,       \
                                   h->stream, ea, eb, 0, h->KF, src, dst, act, x0, x1, p.ny, xlo,     \
@@ -1495,7 +1568,9 @@ static int launch_pair(cfd_handle* h, const double* src, double* dst, const doub
     const uint8_t* act = h->d_active + GHOST * h->plane;
     const int ch = h->pair_chunk;
     constexpr int NT = 256, WC = 240;
-    dim3 block(NT), grid((p.ny + WC - 1) / WC, (p.nx + ch - 1) / ch);
+    const int nchunk = (p.nx + ch - 1) / ch;
+    const TilePlan tp = tile_plan(p.ny, WC, NT, 4, nchunk);
+    dim3 block(NT), grid(tp.nfull * nchunk + tp.npacked);
     // with a neighbouring slab: stored values reach two ghost planes out, once-swept values one
     const int xlo = p.ghost_lo ? -2 : 0, xhi = p.ghost_hi ? p.nx + 1 : p.nx - 1;
     const int xlo1 = p.ghost_lo ? -1 : 0, xhi1 = p.ghost_hi ? p.nx : p.nx - 1;
@@ -1588,23 +1663,29 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->K = make_consts(p->dx, p->dy, p->dz, p->dt, p->lambda, p->suth, p->R, p->cv, p->k, p->dye_f);
     h->KF = make_fast_consts(h->K, p->dx, p->dy, p->dz);
     h->march3_ok = (double)NF3 * (double)h->plane * 8.0 < 4.0e9;
+    h->cus = 256;
+    if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->cus < 1) h->cus = 256;
     h->pair_enabled = getenv("CFD_PAIR") ? atoi(getenv("CFD_PAIR")) != 0 : true;
     if (getenv("CFD_PAIR_CHUNK")) {
         h->pair_chunk = atoi(getenv("CFD_PAIR_CHUNK"));
     } else {
         // The one-pass kernel computes five extra rows per chunk, so chunks should be long; two of its
         // blocks fit a CU, and the whole grid running as one round of blocks was the fastest shape measured.
-        int cus = 256;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
-        const int tiles = (p->ny + 239) / 240;
-        const int chunks = (2 * cus) / tiles > 0 ? (2 * cus) / tiles : 1;
+        const int cus = h->cus;
+        // most chunks whose blocks (tile_plan: the narrow last tile of a row shares blocks) fit one round
+        int chunks = 1;
+        for (int c = 2 * cus; c > 1; --c) {
+            const TilePlan tp = tile_plan(p->ny, 240, 256, 4, c);
+            if (tp.nfull * c + tp.npacked <= 2 * cus) { chunks = c; break; }
+        }
         h->pair_chunk = (p->nx + chunks - 1) / chunks;
         if (h->pair_chunk < 32) h->pair_chunk = 32;
     }
     if (h->pair_chunk < 1) h->pair_chunk = 1;
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
-    if (const char* e = getenv("CFD_CHUNK")) { int v = atoi(e); if (v >= 1) h->chunk = v; }
+    h->chunk_auto = true;
+    if (const char* e = getenv("CFD_CHUNK")) { int v = atoi(e); if (v >= 1) { h->chunk = v; h->chunk_auto = false; } }
     h->variant = -1;
     if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }

@@ -127,6 +127,30 @@ def test_two_sweeps_in_one_pass_equal_two_launches(shape, chunk, monkeypatch):
     assert ga.kernel_timing(2)[1] == 1 and ga.kernel_timing(1)[1] == 0
 
 
+@pytest.mark.parametrize("chunk", [3, 32])
+@pytest.mark.parametrize("shape", [(70, 256), (37, 300), (50, 33), (9, 482), (21, 62), (21, 63), (130, 4096)])
+def test_narrow_last_tile_shares_blocks_bitwise(shape, chunk, monkeypatch):
+    """A row's narrow last tile is handled by single waves, four chunks to a block, in the default streaming
+    kernel and in the two-sweeps kernel; a cell's arithmetic does not depend on the tiling, so two steps must
+    equal, bit for bit, the same steps run with 64-thread blocks (one wave per block: nothing to share) as
+    three launches per step.  Shapes: last tiles of 16, 60, 33, 2, 62 and 63 columns (62 fits the plain sweep's
+    wave but not the two-sweeps kernel's, 63 neither) and the benchmark's width; several chunks, the last
+    shared block partly empty."""
+    params, fields, active = small_case(shape[0], shape[1], 1, 29)
+    monkeypatch.setenv("CFD_CHUNK", str(chunk))
+    monkeypatch.setenv("CFD_PAIR_CHUNK", str(chunk + 1))
+    ga = _gpu_graph(params, fields, active, FAST)
+    monkeypatch.setenv("CFD_VARIANT", "22")
+    gb = _gpu_graph(params, fields, active, FAST)
+    assert ga.pair_available() and not gb.pair_available()
+    ga.step(2)
+    gb.step(2)
+    for rel in range(3):
+        fa, fb = ga.read_fields(rel), gb.read_fields(rel)
+        for k in range(7):
+            assert bits_equal(fa[k], fb[k]), (rel, PROPS[k])
+
+
 def test_filter_is_noop_until_second_step():
     params, fields, active = small_case(9, 8, 1, 12)
     g = _gpu_graph(params, fields, active, 1)
