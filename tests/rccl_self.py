@@ -53,12 +53,25 @@ from helpers import bits_equal
 params, fields, active = small_case(70, 300, 1, 9)
 p = dict(params); p["flags"] = 4
 runs = []
+timing_ok = False
 for kw in (dict(overlap=True), dict(overlap=False), dict(pair=False)):
     g = SlabGraph(p, fields, active, rank=1, world=3, comm=SelfComm(), **kw)
-    g.step(4)
+    if kw.get("overlap"):
+        # per-dispatch timing with launches on two streams, as bench.py has it at N > 1
+        g.step(2)
+        g.graph.set_timing(True)
+        g.step(2)
+        torch.cuda.synchronize()
+        ms0, n0 = g.graph.sweep_timing(reset=True)
+        ms2, n2 = g.graph.kernel_timing(2, reset=True)
+        g.graph.set_timing(False)
+        timing_ok = n0 == 6 and n2 == 2 and 0.0 < ms0 < 100.0 and 0.0 < ms2 < 100.0     # 2 x (interior + two edges), 2 x tail
+    else:
+        g.step(4)
     torch.cuda.synchronize()
     runs.append(([g.read_fields(r) for r in range(3)], g.use_pair()))
     g.close()
 same = all(bits_equal(runs[0][0][r][k], runs[i][0][r][k]) for i in (1, 2) for r in range(3) for k in range(7))
 print("overlapped step ok:", same, "forms:", [u for _, u in runs], "finite:", bool(np.isfinite(runs[0][0][0][3]).all()))
+print("timing across two streams ok:", timing_ok)
 dist.barrier(); dist.destroy_process_group()

@@ -724,6 +724,7 @@ def test_rccl_transport_on_aliased_halo_planes():
     assert "pair available: True" in out.stdout and "finite after the one-pass tail: True" in out.stdout, out.stdout
     # SlabGraph.step's three N > 1 forms over the same transport (the rank as its own neighbour) agree bit for bit
     assert "overlapped step ok: True forms: [True, True, False] finite: True" in out.stdout, out.stdout
+    assert "timing across two streams ok: True" in out.stdout, out.stdout
 
 
 def test_compiled_host_prints_reference_stdout():
