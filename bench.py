@@ -264,6 +264,10 @@ def main():
                               "frac": SWEEPS_PER_STEP * cells_per_gpu * bytes_per_update / (sweep_ms_per_step / 1e3) / 1e9
                               / HBM_PEAK_GBPS}},
     }
+    if world > 1:
+        out["roofline"]["note"] = ("slab run: a plain sweep is three launches (interior planes on the main stream, the "
+                                   "planes next to the neighbours on a side stream beside it, where they share the GPU "
+                                   "with the interior launch and the RCCL transfers); their durations are summed per sweep")
     if strict is not None:
         out["strict"] = strict
     if rank == 0:
