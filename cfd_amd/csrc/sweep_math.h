@@ -435,6 +435,7 @@ struct FastConsts {
     double lambda, suth, R, cv, rcv, k, dyef;
     double c83h, c83n;
     double cp;              // cv + R (streaming forms: convective + pressure-work energy flux in one product)
+    double il, sl;          // 1 / lambda, suth / lambda (mu_stream)
     // streaming form (2-D): centre coefficients and Dye constants with the Dye factor folded in
     double cUa, cVb;        // 2 (kxxm + kyy), 2 (kxx + kyym)
     double kxx2, kyy2;      // 2 kxx, 2 kyy
@@ -454,6 +455,7 @@ inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy, d
     f.lambda = c.lambda; f.suth = c.suth; f.R = c.R; f.cv = c.cv; f.rcv = 1.0 / c.cv; f.k = c.k; f.dyef = c.dyef;
     f.c83h = c.c83h; f.c83n = c.c83n;
     f.cp = c.cv + c.R;
+    f.il = 1.0 / c.lambda;  f.sl = c.suth / c.lambda;
     f.cUa = 2.0 * (f.kxxm + f.kyy);  f.cVb = 2.0 * (f.kxx + f.kyym);
     f.kxx2 = 2.0 * f.kxx;  f.kyy2 = 2.0 * f.kyy;
     f.kxxd = c.dyef * f.kxx;  f.kyyd = c.dyef * f.kyy;  f.cDg = 2.0 * (f.kxxd + f.kyyd);
@@ -608,13 +610,13 @@ enum { S2_U = 0, S2_V, S2_T, S2_DYE };
 
 CFD_HD double mu_stream(const FastConsts& k, double t) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // lambda t^1.5 / (t + S) = lambda t^2 / sqrt(t (t + S)^2): one reciprocal-square-root estimate and
-    // one Newton correction of it
-    const double z = t + k.suth;
+    // lambda t^1.5 / (t + S) = t^2 / sqrt(t ((t + S) / lambda)^2): one reciprocal-square-root estimate and
+    // one Newton correction of it; lambda rides on the shifted temperature, which costs nothing
+    const double z = fma(t, k.il, k.sl);            // (t + S) / lambda
     const double p = t * (z * z);
-    const double y = __builtin_amdgcn_rsq(p);
+    const double y = __builtin_amdgcn_rsq(p);       // ~ lambda / (sqrt(t) (t + S))
     const double d2 = fma(-(p * y), y, 1.0);        // 1 - p y^2 = twice the relative error of y
-    const double base = (k.lambda * t) * (t * y);
+    const double base = (t * t) * y;
     return fma(base, 0.5 * d2, base);
 #else
     return (k.lambda * t) * (sqrt(t) / (t + k.suth));
@@ -668,21 +670,20 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     // ---- centre products
     const double muC = mu_stream(k, c[F2_T]);
     const double a = muC * c[F2_U], b = muC * c[F2_V], g = muC * c[F2_DYE];
-    const double a2 = a * a, b2 = b * b, kt = k.k * c[F2_T];
-    const double px = (kt + fma(k.c83h, a2, k.c83n * a)) + fma(0.5, b2, -b);
-    const double py = (kt + fma(k.c83h, b2, k.c83n * b)) + fma(0.5, a2, -a);
+    const double a2 = a * a, b2 = b * b;
+    const double px = fma(k.k, c[F2_T], fma(k.c83h, a2, k.c83n * a)) + fma(0.5, b2, -b);
+    const double py = fma(k.k, c[F2_T], fma(k.c83h, b2, k.c83n * b)) + fma(0.5, a2, -a);
     // ---- messages
-    const double sxU = k.kxxm * a, txU = k.kxy * dnb;
-    const double sxV = k.kxx * b, txV = k.kxym * dna;
-    const double sxT = k.kxx * px, txT = k.kxy * qq;
-    o.me[S2_U] = sxU + txU;  o.mw[S2_U] = sxU - txU;
-    o.me[S2_V] = sxV + txV;  o.mw[S2_V] = sxV - txV;
-    o.me[S2_T] = sxT + txT;  o.mw[S2_T] = sxT - txT;
+    // second-difference part plus / minus the cross-difference part, the latter folded in with one fused
+    // operation per message (a zero field still yields zero messages)
+    const double sxU = k.kxxm * a, sxV = k.kxx * b, sxT = k.kxx * px;
+    o.me[S2_U] = fma(k.kxy, dnb, sxU);   o.mw[S2_U] = fma(-k.kxy, dnb, sxU);
+    o.me[S2_V] = fma(k.kxym, dna, sxV);  o.mw[S2_V] = fma(-k.kxym, dna, sxV);
+    o.me[S2_T] = fma(k.kxy, qq, sxT);    o.mw[S2_T] = fma(-k.kxy, qq, sxT);
     o.me[S2_DYE] = k.kxxd * g;
-    const double syU = k.kyy * a, tyU = k.kxym * deb;
-    const double syV = k.kyym * b, tyV = k.kxy * dea;
-    o.ms[S2_U] = syU + tyU;  o.mn[S2_U] = syU - tyU;
-    o.ms[S2_V] = syV + tyV;  o.mn[S2_V] = syV - tyV;
+    const double syU = k.kyy * a, syV = k.kyym * b;
+    o.ms[S2_U] = fma(k.kxym, deb, syU);  o.mn[S2_U] = fma(-k.kxym, deb, syU);
+    o.ms[S2_V] = fma(k.kxy, dea, syV);   o.mn[S2_V] = fma(-k.kxy, dea, syV);
     o.ms[S2_T] = k.kyy * py;
     o.ms[S2_DYE] = k.kyyd * g;
     // ---- the cell's own part
