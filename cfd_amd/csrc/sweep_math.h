@@ -1162,35 +1162,40 @@ CFD_HD void phaseA3s(const FastConsts& k, const double c[NF3], const double h[3]
     const double muC = mu_stream(k, c[F3_T]);
     double a[3], a2[3];
     for (int q = 0; q < 3; ++q) { a[q] = muC * c[F3_U + q]; a2[q] = a[q] * a[q]; }
-    const double g = muC * c[F3_DYE], kt = k.k * c[F3_T];
+    const double g = muC * c[F3_DYE];
     double pc[3];
     for (int d = 0; d < 3; ++d) {
-        double v = kt + fma(k.c83h, a2[d], k.c83n * a[d]);
+        double v = fma(k.k, c[F3_T], fma(k.c83h, a2[d], k.c83n * a[d]));
         for (int q = 0; q < 3; ++q)
             if (q != d) v = v + fma(0.5, a2[q], -a[q]);
         pc[d] = v;
     }
     // ---- messages: second-difference part s, cross-difference part t; s + t goes to the lower
-    // neighbour (this cell is its upper one), s - t to the upper neighbour
+    // neighbour (this cell is its upper one), s - t to the upper neighbour.  A one-product t is folded
+    // into s with one fused operation per message.
     {   // X
         const double sU = k.kxxm * a[0], sV = k.kxx * a[1], sW = k.kxx * a[2], sT = k.kxx * pc[0];
-        const double tU = fma(k.kxy, dmu[1][1], k.kxz * dmu[2][2]), tV = k.kxym * dmu[1][0], tW = k.kxzm * dmu[2][0];
+        const double tU = fma(k.kxy, dmu[1][1], k.kxz * dmu[2][2]);
         const double tT = fma(k.kxy, pair[0], k.kxz * pair[1]);
-        o.me[S3_U] = sU + tU; o.me[S3_V] = sV + tV; o.me[S3_W] = sW + tW; o.me[S3_T] = sT + tT; o.me[S3_DYE] = k.kxxd * g;
-        o.mw[S3_U] = sU - tU; o.mw[S3_V] = sV - tV; o.mw[S3_W] = sW - tW; o.mw[S3_T] = sT - tT;
+        o.me[S3_U] = sU + tU; o.me[S3_V] = fma(k.kxym, dmu[1][0], sV); o.me[S3_W] = fma(k.kxzm, dmu[2][0], sW);
+        o.me[S3_T] = sT + tT; o.me[S3_DYE] = k.kxxd * g;
+        o.mw[S3_U] = sU - tU; o.mw[S3_V] = fma(-k.kxym, dmu[1][0], sV); o.mw[S3_W] = fma(-k.kxzm, dmu[2][0], sW);
+        o.mw[S3_T] = sT - tT;
     }
     {   // Y
         const double sU = k.kyy * a[0], sV = k.kyym * a[1], sW = k.kyy * a[2];
-        const double tU = k.kxym * dmu[0][1], tV = fma(k.kxy, dmu[0][0], k.kyz * dmu[2][2]), tW = k.kyzm * dmu[2][1];
-        o.ms[S3_U] = sU + tU; o.ms[S3_V] = sV + tV; o.ms[S3_W] = sW + tW; o.ms[S3_T] = k.kyy * pc[1]; o.ms[S3_DYE] = k.kyyd * g;
-        o.mn[S3_U] = sU - tU; o.mn[S3_V] = sV - tV; o.mn[S3_W] = sW - tW;
+        const double tV = fma(k.kxy, dmu[0][0], k.kyz * dmu[2][2]);
+        o.ms[S3_U] = fma(k.kxym, dmu[0][1], sU); o.ms[S3_V] = sV + tV; o.ms[S3_W] = fma(k.kyzm, dmu[2][1], sW);
+        o.ms[S3_T] = k.kyy * pc[1]; o.ms[S3_DYE] = k.kyyd * g;
+        o.mn[S3_U] = fma(-k.kxym, dmu[0][1], sU); o.mn[S3_V] = sV - tV; o.mn[S3_W] = fma(-k.kyzm, dmu[2][1], sW);
     }
     {   // Z
         const double sU = k.kzz * a[0], sV = k.kzz * a[1], sW = k.kzzm * a[2], sT = k.kzz * pc[2];
-        const double tU = k.kxzm * dmu[0][2], tV = k.kyzm * dmu[1][2], tW = fma(k.kxz, dmu[0][0], k.kyz * dmu[1][1]);
-        const double tT = k.kyz * pair[2];
-        o.mb[S3_U] = sU + tU; o.mb[S3_V] = sV + tV; o.mb[S3_W] = sW + tW; o.mb[S3_T] = sT + tT; o.mb[S3_DYE] = k.kzzd * g;
-        o.mt[S3_U] = sU - tU; o.mt[S3_V] = sV - tV; o.mt[S3_W] = sW - tW; o.mt[S3_T] = sT - tT;
+        const double tW = fma(k.kxz, dmu[0][0], k.kyz * dmu[1][1]);
+        o.mb[S3_U] = fma(k.kxzm, dmu[0][2], sU); o.mb[S3_V] = fma(k.kyzm, dmu[1][2], sV); o.mb[S3_W] = sW + tW;
+        o.mb[S3_T] = fma(k.kyz, pair[2], sT); o.mb[S3_DYE] = k.kzzd * g;
+        o.mt[S3_U] = fma(-k.kxzm, dmu[0][2], sU); o.mt[S3_V] = fma(-k.kyzm, dmu[1][2], sV); o.mt[S3_W] = sW - tW;
+        o.mt[S3_T] = fma(-k.kyz, pair[2], sT);
     }
     // ---- the cell's own part
     const double gU = fma(k.cUa3, a[0], div[E3_U]), gV = fma(k.cVb3, a[1], div[E3_V]), gW = fma(k.cWc3, a[2], div[E3_W]);
