@@ -580,6 +580,9 @@ sweep2d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     // of the block that have not ended).
     const int nv = ny - ytile < WCOLS ? ny - ytile : WCOLS;
     if (wave0 - lb > nv + 1) return;
+    // lanes past the halo lanes sit out the rest of the kernel (masked off: they would compute on nothing at
+    // full power; their wave still takes part in every barrier)
+    if (tl > nv + 1) return;
     const int y = tl < nv ? ytile + tl : (tl == nv ? ytile + nv : ytile - 1);
     const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
     const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
@@ -754,6 +757,7 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     // leave at once (see sweep2d_stream)
     const int nv = ny - ytile < WCOLS ? ny - ytile : WCOLS;
     if (wave0 - lb > nv + 3) return;
+    if (tl > nv + 3) return;    // idle lanes are masked off for the rest of the kernel (see sweep2d_stream)
     // lanes: own columns, then +1 above, -1 below, +2 above, -2 below
     const int y = tl < nv ? ytile + tl
                           : (tl == nv ? ytile + nv : (tl == nv + 1 ? ytile - 1 : (tl == nv + 2 ? ytile + nv + 1 : ytile - 2)));
