@@ -5,7 +5,7 @@ a yardstick for how the scheme itself amplifies a last-bit difference, the oracl
 against the oracle with T*sqrt(T) (all relative to the field scale), and the total-density
 histories.  Writes one JSON document."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # tests/ is one level below the repository root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from cfd_amd import cases
