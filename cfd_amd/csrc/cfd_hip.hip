@@ -941,6 +941,49 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
         mw2[0] = B.mw[0]; mw2[1] = B.mw[1]; mw2[2] = B.mw[2]; mw2D = B.me[S2_DYE];
     };
 
+    // The first three iterations (rows xs-2, xs-1, xs of stage 1): stage 2 would work on rows before a2first, of
+    // which nothing is used, so these iterations run stage 1 only.  Three iterations bring the rings back to their
+    // starting rotation.  Same LDS protocol and barriers as iter.
+    auto iter_stage1 = [&](int j, double* Rw, const double* Rc, const double* Re, double* Vw, double* Vc, double* Ve) {
+        double hx[NF2];
+        x_half_slopes2(Rc, Re, Rw, hx);
+        load_row(clampx(j + 2), Rw);
+        const unsigned char act1 = load_act(clampx(j));
+        double rn[NF2], rs[NF2];
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { rn[f] = lraw1[f][lnc]; rs[f] = lraw1[f][lsc]; }
+        StreamA2 A;
+        phaseA2s<SelPlain>(K, Rc, hx, rn, rs, act1 != 0, A);
+        stream_west(A.q, A.coef, mw1, mw1D);
+        double vnew[NF2];
+        vnew[F2_U] = stream_finish(q1[S2_U], c1[S2_U], A.me[S2_U], lmsg1[0][lnc], lmsg1[4][lsc]);
+        vnew[F2_V] = stream_finish(q1[S2_V], c1[S2_V], A.me[S2_V], lmsg1[1][lnc], lmsg1[5][lsc]);
+        vnew[F2_T] = stream_finish(q1[S2_T], c1[S2_T], A.me[S2_T], lmsg1[2][lnc], lmsg1[2][lsc]);
+        vnew[F2_DYE] = stream_finish(q1[S2_DYE], c1[S2_DYE], A.me[S2_DYE], lmsg1[3][lnc], lmsg1[3][lsc]);
+        vnew[F2_RHO] = rho1;
+        const int r1 = j - 1;
+        if (r1 > xhi1) {
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) vnew[f] = Vc[f];
+        }
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) Ve[f] = vnew[f];
+        if (r1 == xlo1) {
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) { Vc[f] = vnew[f]; Vw[f] = vnew[f]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { lraw1[f][t] = Re[f]; lraw2[f][t] = vnew[f]; }
+        lmsg1[0][t] = A.ms[S2_U]; lmsg1[1][t] = A.ms[S2_V]; lmsg1[2][t] = A.ms[S2_T]; lmsg1[3][t] = A.ms[S2_DYE];
+        lmsg1[4][t] = A.mn[S2_U]; lmsg1[5][t] = A.mn[S2_V];
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { q1[f] = A.q[f]; c1[f] = A.coef[f]; }
+        rho1 = A.rho;
+        mw1[0] = A.mw[0]; mw1[1] = A.mw[1]; mw1[2] = A.mw[2]; mw1D = A.me[S2_DYE];
+    };
+
     const int jb = xs - 2, je = xe + 2;     // stage-1 rows; their indices are clamped where they are used
 #pragma unroll
     for (int u = 0; u < 3; ++u) load_row(clampx(jb - 1 + u), R[u]);
@@ -950,6 +993,11 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): only the previous iteration's operations are pending in the loop
     int j = jb;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        iter_stage1(j, R[u % 3], R[(u + 1) % 3], R[(u + 2) % 3], V[u % 3], V[(u + 1) % 3], V[(u + 2) % 3]);
+        ++j;
+    }
     while (j <= je) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
