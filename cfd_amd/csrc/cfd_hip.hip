@@ -1229,6 +1229,41 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     double mwp[4] = {0, 0, 0, 0}, mwpD = 0.0;
     unsigned char act_j;
 
+    // finish row x: pending values + East message me[] + the in-plane neighbours' messages in LDS; stores
+    // dropped for a row that belongs to the previous chunk
+    auto finish = [&](int x, const double me[NS3], const double pp[NF3]) {
+        const unsigned vs = x >= xs ? vst : 0xFFFFFFF0u;
+        const double nU = stream_finish3(pq[S3_U], pcoef[S3_U], me[S3_U], lmy[0 * NT + lN], lmy[5 * NT + lS],
+                                         lmz[0 * NT + lT], lmz[5 * NT + lB]);
+        const double nV = stream_finish3(pq[S3_V], pcoef[S3_V], me[S3_V], lmy[1 * NT + lN], lmy[6 * NT + lS],
+                                         lmz[1 * NT + lT], lmz[6 * NT + lB]);
+        const double nW = stream_finish3(pq[S3_W], pcoef[S3_W], me[S3_W], lmy[2 * NT + lN], lmy[7 * NT + lS],
+                                         lmz[2 * NT + lT], lmz[7 * NT + lB]);
+        const double nT = stream_finish3(pq[S3_T], pcoef[S3_T], me[S3_T], lmy[3 * NT + lN], lmy[3 * NT + lS],
+                                         lmz[3 * NT + lT], lmz[8 * NT + lB]);
+        const double nD = stream_finish3(pq[S3_DYE], pcoef[S3_DYE], me[S3_DYE], lmy[4 * NT + lN], lmy[4 * NT + lS],
+                                         lmz[4 * NT + lT], lmz[4 * NT + lB]);
+        const PlaneRef d(dst + (long)(x < xlo ? xlo : x) * plane6, pbytes);
+        d.st_nt(vs, (unsigned)F3_RHO * fstride, prho);
+        d.st_nt(vs, (unsigned)F3_T * fstride, nT);
+        d.st_nt(vs, (unsigned)F3_U * fstride, nU);
+        d.st_nt(vs, (unsigned)F3_V * fstride, nV);
+        d.st_nt(vs, (unsigned)F3_W * fstride, nW);
+        d.st_nt(vs, (unsigned)F3_DYE * fstride, nD);
+        if (FILTER) {
+            // Density and Temperature in every cell; U, V, W, Dye only where the cell is active
+            // (coef of U is zero exactly in the cells that keep their values)
+            const PlaneRef pv(fprev + (long)(x < xlo ? xlo : x) * plane6, pbytes);
+            const unsigned vm = pcoef[S3_U] != 0.0 ? vs : 0xFFFFFFF0u;
+            pv.st_nt(vs, (unsigned)F3_RHO * fstride, pp[F3_RHO] + (0.5 * (prho - pp[F3_RHO])));
+            pv.st_nt(vs, (unsigned)F3_T * fstride, pp[F3_T] + (0.5 * (nT - pp[F3_T])));
+            pv.st_nt(vm, (unsigned)F3_U * fstride, pp[F3_U] + (0.5 * (nU - pp[F3_U])));
+            pv.st_nt(vm, (unsigned)F3_V * fstride, pp[F3_V] + (0.5 * (nV - pp[F3_V])));
+            pv.st_nt(vm, (unsigned)F3_W * fstride, pp[F3_W] + (0.5 * (nW - pp[F3_W])));
+            pv.st_nt(vm, (unsigned)F3_DYE * fstride, pp[F3_DYE] + (0.5 * (nD - pp[F3_DYE])));
+        }
+    };
+
     auto row = [&](int j, double* Rw, const double* Rc, const double* Re, bool first) {
         double h[3][NF3];
 #pragma unroll
@@ -1254,39 +1289,7 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
             mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwp[3] = A.mw[3]; mwpD = A.me[S3_DYE];
         }
         stream_west3(A.q, A.coef, mwp, mwpD);
-        {   // finish row j-1 (stores dropped for the row that belongs to the previous chunk)
-            const int x = j - 1;
-            const unsigned vs = x >= xs ? vst : 0xFFFFFFF0u;
-            const double nU = stream_finish3(pq[S3_U], pcoef[S3_U], A.me[S3_U], lmy[0 * NT + lN], lmy[5 * NT + lS],
-                                             lmz[0 * NT + lT], lmz[5 * NT + lB]);
-            const double nV = stream_finish3(pq[S3_V], pcoef[S3_V], A.me[S3_V], lmy[1 * NT + lN], lmy[6 * NT + lS],
-                                             lmz[1 * NT + lT], lmz[6 * NT + lB]);
-            const double nW = stream_finish3(pq[S3_W], pcoef[S3_W], A.me[S3_W], lmy[2 * NT + lN], lmy[7 * NT + lS],
-                                             lmz[2 * NT + lT], lmz[7 * NT + lB]);
-            const double nT = stream_finish3(pq[S3_T], pcoef[S3_T], A.me[S3_T], lmy[3 * NT + lN], lmy[3 * NT + lS],
-                                             lmz[3 * NT + lT], lmz[8 * NT + lB]);
-            const double nD = stream_finish3(pq[S3_DYE], pcoef[S3_DYE], A.me[S3_DYE], lmy[4 * NT + lN], lmy[4 * NT + lS],
-                                             lmz[4 * NT + lT], lmz[4 * NT + lB]);
-            const PlaneRef d(dst + (long)(x < xlo ? xlo : x) * plane6, pbytes);
-            d.st_nt(vs, (unsigned)F3_RHO * fstride, prho);
-            d.st_nt(vs, (unsigned)F3_T * fstride, nT);
-            d.st_nt(vs, (unsigned)F3_U * fstride, nU);
-            d.st_nt(vs, (unsigned)F3_V * fstride, nV);
-            d.st_nt(vs, (unsigned)F3_W * fstride, nW);
-            d.st_nt(vs, (unsigned)F3_DYE * fstride, nD);
-            if (FILTER) {
-                // Density and Temperature in every cell; U, V, W, Dye only where the cell is active
-                // (coef of U is zero exactly in the cells that keep their values)
-                const PlaneRef pv(fprev + (long)(x < xlo ? xlo : x) * plane6, pbytes);
-                const unsigned vm = pcoef[S3_U] != 0.0 ? vs : 0xFFFFFFF0u;
-                pv.st_nt(vs, (unsigned)F3_RHO * fstride, pp[F3_RHO] + (0.5 * (prho - pp[F3_RHO])));
-                pv.st_nt(vs, (unsigned)F3_T * fstride, pp[F3_T] + (0.5 * (nT - pp[F3_T])));
-                pv.st_nt(vm, (unsigned)F3_U * fstride, pp[F3_U] + (0.5 * (nU - pp[F3_U])));
-                pv.st_nt(vm, (unsigned)F3_V * fstride, pp[F3_V] + (0.5 * (nV - pp[F3_V])));
-                pv.st_nt(vm, (unsigned)F3_W * fstride, pp[F3_W] + (0.5 * (nW - pp[F3_W])));
-                pv.st_nt(vm, (unsigned)F3_DYE * fstride, pp[F3_DYE] + (0.5 * (nD - pp[F3_DYE])));
-            }
-        }
+        finish(j - 1, A.me, pp);     // stores dropped for the row that belongs to the previous chunk
         __syncthreads();        // every read of row j's stored values and row j-1's messages is done
 #pragma unroll
         for (int f = 0; f < NF3; ++f) lraw[f * NT + tw] = Re[f];
@@ -1304,24 +1307,80 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
         act_j = act_n;
     };
 
+    // West / East messages of a row whose own values this block does not finish (the first and the last row
+    // of a chunk): phase A with zero x half-slopes, of which only the two messages are used -- they depend on
+    // the y and z faces and the centre products alone, and the compiler drops the rest.  LIGHT: see sweep2d_stream.
+    constexpr bool LIGHT = RD == 3;
+    auto x_messages = [&](const double* Rc, double me[NS3], double mw[4]) {
+        double h[3][NF3];
 #pragma unroll
-    for (int u = 0; u < RD; ++u) load_row(clampx(j0 - 1 + u), R[u]);
-    act_j = load_act(j0);
+        for (int f = 0; f < NF3; ++f) {
+            h[0][f] = 0.0;
+            h[1][f] = half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS]);
+            h[2][f] = half_slope(lraw[f * NT + lT], Rc[f], lraw[f * NT + lB]);
+        }
+        StreamA3 A;
+        phaseA3s(K, Rc, h, mask_of(true), A);
 #pragma unroll
-    for (int f = 0; f < NF3; ++f) lraw[f * NT + tw] = R[1][f];
+        for (int e = 0; e < NS3; ++e) me[e] = A.me[e];
+        mw[0] = A.mw[0]; mw[1] = A.mw[1]; mw[2] = A.mw[2]; mw[3] = A.mw[3];
+    };
+
     // the message tiles are read (and the result dropped) in the first iteration: define them
     for (int e = 0; e < 8; ++e) lmy[e * NT + tw] = 0.0;
     for (int e = 0; e < 9; ++e) lmz[e * NT + tw] = 0.0;
-    __syncthreads();
+    int j, jfirst;
+    if (LIGHT && j0 < xs) {
+        // row xs-1 belongs to the previous chunk and only sends its message to row xs
+        load_row(j0, R[0]);
+        load_row(xs, R[1]);
+        load_row(clampx(xs + 1), R[2]);
+        act_j = load_act(xs);
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) lraw[f * NT + tw] = R[0][f];
+        __syncthreads();
+        double me0[NS3];
+        x_messages(R[0], me0, mwp);
+        mwpD = me0[S3_DYE];
+        __syncthreads();            // every read of row xs-1's stored values is done
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) lraw[f * NT + tw] = R[1][f];
+        __syncthreads();
+        j = xs;
+        jfirst = j0 - 1;
+    } else {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) load_row(clampx(j0 - 1 + u), R[u]);
+        act_j = load_act(j0);
+#pragma unroll
+        for (int f = 0; f < NF3; ++f) lraw[f * NT + tw] = R[1][f];
+        __syncthreads();
+        j = j0;
+        jfirst = j0;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): see sweep2d_stream
-    int j = j0;
-    while (j <= j1) {
+    const int jl = LIGHT ? j1 - 1 : j1;     // row j1 = xe only sends its message to row xe-1
+    int rot = 0;
+    while (j <= jl) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
-            row(j, R[u % RD], R[(u + 1) % RD], R[(u + 2) % RD], j == j0);
+            row(j, R[u % RD], R[(u + 1) % RD], R[(u + 2) % RD], j == jfirst);
             ++j;
-            if (j > j1) break;
+            rot = (u + 1) % RD;
+            if (j > jl) break;
         }
+    }
+    if (LIGHT) {
+        double me1[NS3], mwu[4], pp[NF3];
+        if (FILTER) {
+            const PlaneRef q(fpp + (long)(xe - 1) * plane6, pbytes);
+#pragma unroll
+            for (int f = 0; f < NF3; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
+        }
+        if (rot == 0) x_messages(R[1 % RD], me1, mwu);
+        else if (rot == 1) x_messages(R[2 % RD], me1, mwu);
+        else x_messages(R[3 % RD], me1, mwu);
+        finish(xe - 1, me1, pp);
     }
 }
 
