@@ -70,6 +70,84 @@ def test_term_counts_match_reference_dump():
     assert counts[A.TEMPERATURE] == (14, 60)
 
 
+def _term_pins():
+    with open(os.path.join(GOLD, "term_pins.json")) as f:
+        return json.load(f)["equations"]
+
+
+_DUMP_EQ = {"Density": A.continuity, "U": A.uMomentum, "V": A.vMomentum, "W": A.wMomentum, "Temperature": A.energy}
+_DIR_NAME = {A.X: "X", A.Y: "Y", A.Z: "Z"}
+_SIDE_NAME = {A.EAST: "East", A.WEST: "West", A.NORTH: "North", A.SOUTH: "South", A.TOP: "Top", A.BOTTOM: "Bottom"}
+
+
+def _instantiate_at_interior_cell(name):
+    """The named equation instantiated at the centre cell of a perturbed 3 x 3 x 3 grid whose velocity
+    components, Density and Temperature are all positive (so that every flux term has a definite sign)."""
+    params, fields, active = small_case(3, 3, 3, seed=1)
+    fields = [np.array(f, dtype=np.float64) for f in fields]
+    fields[1] = np.abs(fields[1]) + 0.1
+    fields[2] = np.abs(fields[2]) + 0.1
+    g = A.build_graph((2, 2, 2), None, fields, np.ones(27, np.uint8),
+                      cellLength=[params["dx"], params["dy"], params["dz"]])
+    return A.getDiscEqInstance(_DUMP_EQ[name](g), (13, 0)), g
+
+
+@pytest.mark.parametrize("name", ["U", "V", "W", "Temperature"])
+def test_rhs_term_sequence_matches_reference_dump(name):
+    """The reference's own dump of its instantiated equations (src/old test.txt:12,18,24,30; printed in
+    reverse, src/Main.hs:324) fixes, for every right-hand-side term in list order, the direction of the
+    inner derivative and the face of the outer one: 18 terms for each momentum equation, 60 for energy.
+    The restatement's instantiated lists must show the same sequence (term order = summation order)."""
+    want = [(d, s) for d, s, _ in _term_pins()[name]["rhs"]]
+    inst, _ = _instantiate_at_interior_cell(name)
+    got = []
+    for t in inst.rhs:
+        assert isinstance(t, A.Derivative_adj)
+        got.append((_DIR_NAME[t.denom], _SIDE_NAME[t.centered]))
+    assert got == want
+
+
+@pytest.mark.parametrize("name", ["Density", "U", "V", "W", "Temperature"])
+def test_lhs_order_and_signs_match_reference_dump(name):
+    """src/old test.txt:8,14,20,26,32: the left-hand side is the Unknown (time term, upper side) first, then
+    constants that alternate in sign -- upper face +, lower face - (a lower-face term is multiplied by -1,
+    src/CalculusUtils.hs:72; zeros print their sign) -- in the order time, x-flux, y-flux, z-flux pairs and,
+    for momentum, the pressure pair last (energy: the three pressure-work pairs).  Same kinds, same order,
+    same signs in the restatement's instantiated list."""
+    want = _term_pins()[name]["lhs"]
+    inst, _ = _instantiate_at_interior_cell(name)
+    assert len(inst.lhs) == len(want)
+    for i, (t, (kind, v)) in enumerate(zip(inst.lhs, want)):
+        if kind == "X":
+            assert isinstance(t, A.Unknown), (name, i)
+            got = t.coeff
+        else:
+            assert isinstance(t, A.Constant), (name, i)
+            got = t.val
+        # The dump's V and W fields are zero, so its pressure pair is the only momentum pair with a sign of
+        # its own; every other pair alternates +, - by construction and is checked as such.
+        assert math.copysign(1.0, got) == math.copysign(1.0, v), (name, i, got, v)
+    if name == "Density":
+        assert len(inst.rhs) == 1 and isinstance(inst.rhs[0], A.Constant) and inst.rhs[0].val == 0.0
+
+
+@pytest.mark.parametrize("name,line,printed", [("Density", 10, "1.00005"), ("U", 16, "0.9999416666666667"),
+                                               ("V", 22, "-1.0e-4"), ("W", 28, "-1.0e-4"),
+                                               ("Temperature", 34, "1.0000622222222222")])
+def test_solve_unknown_on_the_dumped_equations(name, line, printed):
+    """Five more reference-held known answers for solveUnknown (src/CalculusUtils.hs:36-52): the dump prints
+    each equation's evaluated terms and then `solveUnknown` of it (src/old test.txt:10,16,22,28,34).  Feeding
+    the printed term values (shortest round-trip digits, i.e. the exact doubles) back through the
+    restatement in list order must reproduce the printed result digit for digit: pins the fold order
+    (left folds from 0), the sign convention and the final division."""
+    from cfd_amd.solver import _hs_show_double
+    eq = _term_pins()[name]
+    lhs = [A.Unknown(v) if k == "X" else A.Constant(v) for k, v in eq["lhs"]]
+    rhs = [A.Constant(t[-1]) for t in eq["rhs"]]
+    got = A.solveUnknown(A.Equation(lhs, rhs, None), (0, 0), None)
+    assert _hs_show_double(got) == printed, (name, line, got)
+
+
 # ---- limiter -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("a,b,want", [
     (1.0, 2.0, 2.0), (2.0, 1.0, 2.0), (1.0, 3.0, 2.0), (3.0, 1.0, 2.0), (1.0, 1.0, 1.0),
