@@ -20,6 +20,14 @@ sweep against the strict form, see tests); --arith strict runs the reference's o
 (bit-identical to the CPU oracle).  The strict kernel is also timed on a few steps and reported
 under "strict" in the same JSON line.
 
+Launch: with --gpus N > 1 and no WORLD_SIZE in the environment the command starts the N ranks itself (a
+child `python -m torch.distributed.run --nproc-per-node N bench.py ...`, started before this process has made
+any GPU call), relays rank 0's JSON line and exits with the children's status; under a launcher (WORLD_SIZE
+set) it is one rank.  Warm-up: --warmup steps, then more steps until at least --warmup-seconds (0.5 s) of
+steps have run, so that a short run is timed at the clock the GPU sustains, not at its boost clock; the extra
+steps are reported as "warmup_extra_steps".  --dry-run rehearses the launch path without a GPU (gloo
+rendezvous, barrier, max-over-ranks reduction, no compute): its JSON line carries "dry_run": true and no value.
+
 Prints ONE JSON line (rank 0): whole-job cell-updates/s with the inputs already resident in
 HBM, the sweep kernel's roofline object (HIP-event kernel time measured in the timed region)
 and, at N = 1, the CPU baseline (the C restatement under oracle/, timed on a bounded sample).
@@ -55,6 +63,10 @@ def parse():
     ap.add_argument("--arith", choices=("fast", "strict"), default="fast")
     ap.add_argument("--dt", type=float, default=1e-7)
     ap.add_argument("--flags", type=int, default=0, help="extra cfd_params.flags (1 = one-thread-per-cell kernel)")
+    ap.add_argument("--warmup-seconds", type=float, default=0.5,
+                    help="keep warming up until this much time has been spent in steps")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse launch + rendezvous + reduction without a GPU (gloo, no compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="edge of the square CPU-baseline sample grid")
     return ap.parse_args()
@@ -91,12 +103,25 @@ def cpu_baseline(edge):
                                      "sample": "the reference's configuration, %d steps, %.1f s" % (nsteps1, dt1)}}
 
 
+def kernel_source_hash():
+    """SHA-256 of the kernel sources: counter records are valid for the build they were taken on only."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("cfd_hip.hip", "sweep_math.h"):
+        with open(os.path.join(ROOT, "cfd_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from a separate rocprofv3 --pmc pass, if one was recorded."""
+    """HBM bytes per launch of `kernel` from a separate rocprofv3 --pmc pass (scripts/record_traffic.py), if one
+    was recorded FOR THIS BUILD of the kernels: a record stamped with another source hash is not reported."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
+        if rec.get("kernel_source_sha256") != kernel_source_hash():
+            return None
         for entry in rec.get(workload, []):
             if kernel.startswith(entry.get("kernel_prefix", "\0")):
                 return entry.get("hbm_bytes_per_launch")
@@ -105,19 +130,85 @@ def measured_traffic(workload, kernel):
         return None
 
 
-def main():
-    a = parse()
+def spawn_ranks(a):
+    """--gpus N > 1 outside a launcher: start the N ranks as fresh processes (this process has made no GPU
+    call and imports no torch), relay rank 0's JSON line, exit with the launcher's status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    json_lines = []
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            json_lines.append(line.rstrip("\n"))
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if json_lines:
+        print(json_lines[-1], flush=True)
+    raise SystemExit(rc if rc else (0 if json_lines else 1))
+
+
+def dry_run(a, world, rank):
+    """The launch path without a GPU: rendezvous over gloo, barrier, the max-over-ranks reduction, one line."""
     import torch
     import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "fp64 cell-updates/sec", "value": None, "unit": "cell-updates/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "dry_run": True,
+                          "note": "launch-path rehearsal: no GPU, no compute, nothing measured"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
+
+def sclk_reader(device_index):
+    """Returns a function that reads the GPU's current shader clock in MHz from sysfs (None where unreadable)."""
+    import glob
+    cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if not cands:
+        return lambda: None
+    path = cands[min(device_index, len(cands) - 1)]
+
+    def read():
+        try:
+            with open(path) as f:
+                for line in f:
+                    if line.rstrip().endswith("*"):
+                        return int(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+    return read
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (a.gpus, a.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if a.dry_run:
+        return dry_run(a, world, rank)
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -152,16 +243,34 @@ def main():
         torch.cuda.synchronize()
         g.sync()
 
+    tw = time.perf_counter()
     for _ in range(a.warmup):
         g.step(1)
     barrier()
+    # warm up by time as well: every rank derives the same number of extra steps from the slowest rank's time
+    tw = time.perf_counter() - tw
+    if world > 1:
+        t = torch.tensor([tw], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tw = float(t.item())
+    warmup_extra = 0
+    if tw < a.warmup_seconds:
+        per_step = tw / a.warmup if a.warmup > 0 else 1e-3
+        warmup_extra = min(100000, int((a.warmup_seconds - tw) / max(per_step, 1e-6)) + 1)
+        for _ in range(warmup_extra):
+            g.step(1)
+        barrier()
+    read_sclk = sclk_reader(local_rank)
+    sclk = []
     g.graph.set_timing(True)
     g.graph.sweep_timing(reset=True)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         g.step(1)
+    sclk.append(read_sclk())        # the host has queued the steps and the GPU is still running them
     barrier()
     elapsed = time.perf_counter() - t0
+    sclk.append(read_sclk())
     kernel_ms, launches = g.graph.sweep_timing(reset=True)
     fused_ms, fused_launches = g.graph.kernel_timing(1, reset=True)
     pair_ms, pair_launches = g.graph.kernel_timing(2, reset=True)
@@ -241,6 +350,9 @@ def main():
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
+        "warmup_extra_steps": warmup_extra,
+        "sclk_mhz": {"while_queued_steps_run": sclk[0], "after_the_run": sclk[1],
+                     "source": "pp_dpm_sclk (the active DPM level; the in-kernel clock under fp64 load reads lower)"},
         "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong" if a.strong else "weak",

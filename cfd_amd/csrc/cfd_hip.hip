@@ -1682,6 +1682,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                 case 14: LAUNCH_STREAM3(12, 16, 256, 2, 4); break;
                 case 15: LAUNCH_STREAM3(4, 16, 128, 2, 3); break;
                 case 16: LAUNCH_STREAM3(26, 16, 512, 2, 3); break;
+                case 17: LAUNCH_STREAM3(12, 16, 256, 3, 3); break;
                 case 1: LAUNCH_MARCH3(MathFast3, h->KF, 8, 32, 2); break;
                 case 2: LAUNCH_MARCH3(MathFast3, h->KF, 16, 32, 1); break;
                 case 3: LAUNCH_MARCH3(MathFast3, h->KF, 8, 16, 2); break;
@@ -2052,6 +2053,12 @@ int cfd_sweep_end_on(cfd_handle* h, void* stream) {
 int cfd_step(cfd_handle* h, int nsteps) {
     if (!h) return fail(CFD_E_ARG, "cfd_step: null handle");
     if (nsteps < 0) return fail(CFD_E_ARG, "cfd_step: nsteps must be >= 0");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_step: a split sweep is open (call cfd_sweep_end first)");
+    // A slab's ghost planes must be refreshed by the host before every sweep (cfd_halo_planes*), which a
+    // whole step in one call cannot do: its second sweep would read planes the neighbour has not sent.
+    if (h->p.ghost_lo || h->p.ghost_hi)
+        return fail(CFD_E_STATE, "cfd_step: this handle is a slab (ghost_lo / ghost_hi); drive it sweep by sweep with a "
+                                 "halo exchange before each (cfd_halo_planes, cfd_sweep_begin / cfd_sweep_end)");
     HIP_TRY(hipSetDevice(h->device));
     for (int i = 0; i < nsteps; ++i) {
         // The filter after the first and second sweep of a step writes values that the filter
@@ -2072,6 +2079,7 @@ int cfd_step(cfd_handle* h, int nsteps) {
 
 int cfd_total_density(cfd_handle* h, double* out) {
     if (!h || !out) return fail(CFD_E_ARG, "cfd_total_density: null pointer");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_total_density: a split sweep is open (call cfd_sweep_end first)");
     HIP_TRY(hipSetDevice(h->device));
     const int t = (h->cmt + 2) % 3;
     const int f = h->two_d ? F2_RHO : 3;
@@ -2093,6 +2101,7 @@ int cfd_read_fields(cfd_handle* h, int slot_rel, double* const out[CFD_NPROP]) {
     if (slot_rel < 0 || slot_rel > 2) return fail(CFD_E_ARG, "cfd_read_fields: slot_rel must be 0, 1 or 2");
     for (int i = 0; i < CFD_NPROP; ++i)
         if (!out[i]) return fail(CFD_E_ARG, "cfd_read_fields: null output pointer");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_read_fields: a split sweep is open (call cfd_sweep_end first)");
     HIP_TRY(hipSetDevice(h->device));
     const int t = ((h->cmt - slot_rel) % 3 + 3) % 3;
     const int* prop = h->two_d ? kProp2 : kProp3;
@@ -2106,6 +2115,45 @@ int cfd_read_fields(cfd_handle* h, int slot_rel, double* const out[CFD_NPROP]) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->two_d) std::memset(out[2], 0, n * sizeof(double));   // W is exactly +0 throughout
     std::memcpy(out[5], h->mew.data(), n * sizeof(double));
+    return CFD_OK;
+}
+
+int cfd_write_fields(cfd_handle* h, int slot_rel, const double* const in[CFD_NPROP]) {
+    if (!h || !in) return fail(CFD_E_ARG, "cfd_write_fields: null pointer");
+    if (slot_rel < 0 || slot_rel > 2) return fail(CFD_E_ARG, "cfd_write_fields: slot_rel must be 0, 1 or 2");
+    for (int i = 0; i < CFD_NPROP; ++i)
+        if (!in[i]) return fail(CFD_E_ARG, "cfd_write_fields: null input pointer");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_write_fields: a split sweep is open (call cfd_sweep_end first)");
+    const size_t n = (size_t)h->p.nx * h->plane;
+    if (h->two_d) {
+        // the handle holds no W at all: a W that is not identically +0 cannot be represented
+        const uint64_t* wb = reinterpret_cast<const uint64_t*>(in[2]);
+        for (size_t i = 0; i < n; ++i)
+            if (wb[i] != 0)
+                return fail(CFD_E_STATE, "cfd_write_fields: W is not identically +0 but the handle was created in its "
+                                         "2-D form (nz == 1, W == 0); create it with CFD_FLAG_FORCE_3D");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const int t = ((h->cmt - slot_rel) % 3 + 3) % 3;
+    const int* prop = h->two_d ? kProp2 : kProp3;
+    const size_t row = h->plane * sizeof(double);
+    for (int f = 0; f < h->nf; ++f) {
+        double* d = slot_base(h, t) + (size_t)f * h->plane;
+        HIP_TRY(hipMemcpy2DAsync(d, (size_t)h->nf * row, in[prop[f]], row, row, h->p.nx, hipMemcpyHostToDevice,
+                                 h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (slot_rel == 0) h->mew.assign(in[5], in[5] + n);     // stored Mew: one copy serves every slot (never updated)
+    return CFD_OK;
+}
+
+int cfd_set_time(cfd_handle* h, int curr_mod_time, int curr_abs_time) {
+    if (!h) return fail(CFD_E_ARG, "cfd_set_time: null handle");
+    if (curr_mod_time < 0 || curr_mod_time > 2) return fail(CFD_E_ARG, "cfd_set_time: curr_mod_time must be 0, 1 or 2");
+    if (curr_abs_time < 0) return fail(CFD_E_ARG, "cfd_set_time: curr_abs_time must be >= 0");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_set_time: a split sweep is open (call cfd_sweep_end first)");
+    h->cmt = curr_mod_time;
+    h->cat = curr_abs_time;
     return CFD_OK;
 }
 

@@ -94,6 +94,31 @@ class AdjGraph:
         check(self._lib.cfd_read_fields(self._h, int(slot_rel), _capi.ptr_array(out)))
         return out
 
+    def write_fields(self, fields, slot_rel=0):
+        """Overwrites time slot currModTime - slot_rel with seven host arrays (the inverse of read_fields)."""
+        f = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in fields]
+        if len(f) != _capi.CFD_NPROP or any(x.size != self.n for x in f):
+            raise ValueError("fields must be 7 arrays of nx*ny*nz values")
+        check(self._lib.cfd_write_fields(self._h, int(slot_rel), _capi.ptr_array(f)))
+        return self
+
+    def set_time(self, currModTime, currAbsTime):
+        check(self._lib.cfd_set_time(self._h, int(currModTime), int(currAbsTime)))
+        return self
+
+    def checkpoint(self):
+        """Everything a resumed run needs: (currModTime, currAbsTime, [slot 0, slot -1, slot -2])."""
+        cmt, cat = self._time()
+        return cmt, cat, [self.read_fields(r) for r in range(3)]
+
+    def restore(self, state):
+        """Puts a checkpoint() back (into this or another graph of the same shape)."""
+        cmt, cat, slots = state
+        self.set_time(cmt, cat)
+        for r in range(3):
+            self.write_fields(slots[r], r)
+        return self
+
     def property_slice(self, prp, z_level=None, slot_rel=0):
         """adjGraphToGrid (src/Main.hs:339-346): output property `prp` (name or index in OUTPUT_PROPERTIES)
         of the cells with z == z_level as an (nx, ny) array; z_level defaults to the reference's

@@ -102,7 +102,9 @@ void cfd_destroy(cfd_handle *h);
 /* runSingleStep (src/Main.hs:192-200), nsteps times: three sweeps, the first advancing the
  * time slot, each followed by the time filter.  Only the third filter of a step is live (the
  * first two are overwritten from the same inputs), so it is applied once, fused into the third
- * sweep's kernel; results are identical to cfd_sweep x3 + cfd_time_filter x3. */
+ * sweep's kernel; results are identical to cfd_sweep x3 + cfd_time_filter x3.
+ * A slab (ghost_lo or ghost_hi set) needs its ghost planes exchanged before every sweep, which one
+ * call for a whole step cannot do: CFD_E_STATE; drive a slab sweep by sweep (see the halo section). */
 int cfd_step(cfd_handle *h, int nsteps);
 
 /* applyDiffEq_adj calcSteps_adj step_time (src/Main.hs:202-226): one forward-Euler sweep of
@@ -161,6 +163,21 @@ int cfd_total_density(cfd_handle *h, double *out);
 /* Copies one time slot to the host.  slot_rel: 0 = currModTime, 1 = one back, 2 = two back
  * (pushBackTime, src/SolutionDomain.hs:422-423).  out[i] receives nx*ny*nz doubles. */
 int cfd_read_fields(cfd_handle *h, int slot_rel, double *const out[CFD_NPROP]);
+
+/* The inverse of cfd_read_fields: overwrites one time slot (owned planes) with host fields, in[i] holding
+ * nx*ny*nz doubles in propIndex order.  With cfd_set_time this restores a saved AdjGraph -- its three
+ * grids, currModTime and currAbsTime (src/SolutionDomain.hs:53-57); the reference keeps that state only in
+ * the accumulator of its solve loop (src/Main.hs:278-306), so a run there cannot be resumed.  To restore:
+ * cfd_create with any fields of the right shape, cfd_set_time, then cfd_write_fields for slot_rel 0, 1, 2.
+ * Stored Mew is the same in every slot (no equation updates it): the copy given with slot_rel 0 is kept.
+ * A handle in its 2-D form (cfd_live_fields == 5) holds no W and rejects a W that is not identically +0
+ * with CFD_E_STATE.  Ghost planes are not touched (the host refreshes them before every sweep). */
+int cfd_write_fields(cfd_handle *h, int slot_rel, const double *const in[CFD_NPROP]);
+
+/* Sets currModTime (0..2, the slot the next sweep reads) and currAbsTime (the number of time-advancing
+ * sweeps so far; the time filter is a no-op while it is <= 1) of the AdjGraph, src/SolutionDomain.hs:55-56.
+ * Slots keep their contents: slot_rel 0 afterwards names slot curr_mod_time. */
+int cfd_set_time(cfd_handle *h, int curr_mod_time, int curr_abs_time);
 
 /* Output properties, numbered as the reference's Property enum (src/SolutionDomain.hs:30). */
 enum {

@@ -69,3 +69,39 @@ def field_errors(got, want):
         d = float(np.max(np.abs(np.asarray(got[k]) - np.asarray(want[k]))))
         out.append(0.0 if d == 0 else d / sc if sc > 0 else float("inf"))
     return out
+
+
+def elem_rel_errors(got, want, floor=1e-3):
+    """Per-property ELEMENT-relative error of two 7-field lists: max over cells of |a-b| / max(|b|, floor*scale),
+    scale = max|b| of that property itself (so V and W are measured against their own magnitude, not against
+    U's).  The floor keeps cells where a field passes through zero from dividing rounding noise by nothing."""
+    out = []
+    for k in range(7):
+        a, b = np.asarray(got[k], np.float64), np.asarray(want[k], np.float64)
+        d = np.abs(a - b)
+        if not d.any():
+            out.append(0.0)
+            continue
+        scale = float(np.max(np.abs(b)))
+        if scale == 0:
+            out.append(float("inf"))
+            continue
+        out.append(float(np.max(d / np.maximum(np.abs(b), floor * scale))))
+    return out
+
+
+def own_scale_errors(got, want, floor=1e-2):
+    """Per-property error relative to THAT property's own largest magnitude: max|a-b| / max|b_k|.  A velocity
+    component smaller than `floor` times the largest velocity component is measured against that floor instead:
+    the components of one vector share their absolute rounding noise (every flux of V carries U), so a V that is
+    1e-5 of U cannot be resolved to 1e-12 of itself by any arithmetic -- the reference's own is no exception (a
+    one-ulp change of the viscosity moves such a V by 1e-9 of itself, profiles/r02/error_metrics_fast_sweep.txt)."""
+    vs = max(float(np.max(np.abs(want[k]))) for k in (0, 1, 2))
+    out = []
+    for k in range(7):
+        d = float(np.max(np.abs(np.asarray(got[k]) - np.asarray(want[k]))))
+        sc = float(np.max(np.abs(want[k])))
+        if k < 3:
+            sc = max(sc, floor * vs)
+        out.append(0.0 if d == 0 else d / sc if sc > 0 else float("inf"))
+    return out

@@ -1,0 +1,35 @@
+"""bench.py's own launch path for N > 1, rehearsed on the CPU: `python bench.py --gpus 2 --dry-run` must start
+two fresh ranks, rendezvous (gloo), reduce, print ONE JSON line with n_gpus = 2 and exit 0; without --dry-run and
+without a GPU the ranks fail loudly and the parent passes their failure on."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                           *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    r = _run("--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["value"] is None
+
+
+def test_bench_gpus_2_without_a_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: the real multi-rank run is not a CPU test")
+    r = _run()
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
