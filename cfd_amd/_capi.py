@@ -17,7 +17,7 @@ CFD_FLAG_DEFAULT, CFD_FLAG_SIMPLE_KERNEL, CFD_FLAG_FORCE_3D, CFD_FLAG_FAST_MATH 
 # every symbol include/cfd_hip.h declares
 EXPORTS = [
     "cfd_default_params", "cfd_create", "cfd_destroy", "cfd_step", "cfd_sweep", "cfd_sweep_and_filter", "cfd_sweep_begin", "cfd_sweep_end", "cfd_sweep_begin_depth", "cfd_sweep_end_on", "cfd_sweep_pair_and_filter", "cfd_time_filter",
-    "cfd_total_density", "cfd_read_fields", "cfd_write_fields", "cfd_set_time", "cfd_property_slice", "cfd_time", "cfd_last_error", "cfd_halo_planes", "cfd_halo_planes_depth", "cfd_set_ghost_active", "cfd_pair_available",
+    "cfd_total_density", "cfd_total_density_noalloc", "cfd_read_fields", "cfd_write_fields", "cfd_set_time", "cfd_property_slice", "cfd_time", "cfd_last_error", "cfd_halo_planes", "cfd_halo_planes_depth", "cfd_set_ghost_active", "cfd_pair_available",
     "cfd_stream", "cfd_set_stream", "cfd_kernel_name", "cfd_sync", "cfd_set_timing", "cfd_sweep_timing", "cfd_kernel_timing", "cfd_live_fields",
 ]
 
@@ -75,6 +75,7 @@ def load():
     L.cfd_sweep_end_on.argtypes = [H, ctypes.c_void_p]
     L.cfd_sweep_pair_and_filter.argtypes = [H]
     L.cfd_total_density.argtypes = [H, ctypes.POINTER(ctypes.c_double)]
+    L.cfd_total_density_noalloc.argtypes = [H, ctypes.c_void_p]
     L.cfd_read_fields.argtypes = [H, ctypes.c_int, PP]
     L.cfd_write_fields.argtypes = [H, ctypes.c_int, PP]
     L.cfd_set_time.argtypes = [H, ctypes.c_int, ctypes.c_int]

@@ -1508,6 +1508,25 @@ sum_field_stage2(const double* __restrict__ partial, int n, double* __restrict__
     if (threadIdx.x == 0) out[0] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
 }
 
+// Partial sums of cfd_total_density_noalloc: one array per GPU, part of the loaded code object (nothing is
+// allocated for it at run time; each GPU the library runs on holds its copy until the process ends).  In host
+// code the name `scratch` is only a handle for hipGetSymbolAddress: the address the kernels get is the
+// per-device pointer kept in g_scratch.
+static constexpr int SCRATCH_PARTIALS = 1024;
+static __device__ __align__(256) double scratch[SCRATCH_PARTIALS];
+static constexpr int MAX_DEVICES = 64;
+static double* g_scratch[MAX_DEVICES] = {};      // device ordinal -> address of that GPU's copy of `scratch`
+
+// Looks up this GPU's copy of `scratch` (once per device; the device must be current).
+static int scratch_setup(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(CFD_E_ARG, "device ordinal beyond the library's table of 64");
+    if (g_scratch[device]) return CFD_OK;
+    double* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    g_scratch[device] = ptr;
+    return CFD_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1868,6 +1887,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
         }                                                                                      \
     } while (0)
 
+    if (int rc = scratch_setup(dev)) { cfd_destroy(h); return rc; }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) {
         CREATE_TRY(hipMalloc((void**)&h->buf[i], h->slot_elems * sizeof(double)));
@@ -1875,7 +1895,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     }
     CREATE_TRY(hipMalloc((void**)&h->d_active, (size_t)(p->nx + 2 * GHOST) * h->plane));
     CREATE_TRY(hipMemsetAsync(h->d_active, 0, (size_t)(p->nx + 2 * GHOST) * h->plane, h->stream));
-    h->n_partial = 1024;
+    h->n_partial = SCRATCH_PARTIALS;     // cfd_total_density_noalloc uses the same geometry
     CREATE_TRY(hipMalloc((void**)&h->d_partial, (h->n_partial + 1) * sizeof(double)));
     CREATE_TRY(hipMemcpyAsync(h->d_active + GHOST * h->plane, active, n, hipMemcpyHostToDevice, h->stream));
     // slot 0 from the host fields, plane-interleaved; then slots 1, 2 and scratch as device copies
@@ -2093,6 +2113,26 @@ int cfd_total_density(cfd_handle* h, double* out) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->d_partial + h->n_partial, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return CFD_OK;
+}
+
+int cfd_total_density_noalloc(cfd_handle* h, double* d_out) {
+    if (!h || !d_out) return fail(CFD_E_ARG, "cfd_total_density_noalloc: null pointer");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_total_density_noalloc: a split sweep is open (call cfd_sweep_end first)");
+    const long total = (long)h->p.nx * (long)h->plane;
+    if (total > CFD_NOALLOC_MAX_CELLS)
+        return fail(CFD_E_ARG, "cfd_total_density_noalloc: more than CFD_NOALLOC_MAX_CELLS (2^31) owned cells");
+    double* part = g_scratch[h->device];      // set by cfd_create on this device
+    if (!part) return fail(CFD_E_STATE, "cfd_total_density_noalloc: the device's scratch array was not set up");
+    HIP_TRY(hipSetDevice(h->device));
+    const int t = (h->cmt + 2) % 3;
+    const int f = h->two_d ? F2_RHO : 3;
+    int nb = (int)((total + 255) / 256);        // the same launch geometry as cfd_total_density: the same bits
+    if (nb > SCRATCH_PARTIALS) nb = SCRATCH_PARTIALS;
+    hipLaunchKernelGGL(sum_field_stage1, dim3(nb), dim3(256), 0, h->stream, slot_base(h, t), (long)h->plane, h->nf,
+                       f, h->p.nx, part);
+    hipLaunchKernelGGL(sum_field_stage2, dim3(1), dim3(256), 0, h->stream, part, nb, d_out);
+    HIP_TRY(hipGetLastError());
     return CFD_OK;
 }
 

@@ -160,6 +160,19 @@ int cfd_sweep_end_on(cfd_handle *h, void *stream);
  * The reference folds sequentially; this is a tree reduction, so the last bits may differ. */
 int cfd_total_density(cfd_handle *h, double *out);
 
+/* totalDensity for callers that cannot allocate or synchronise (code under HIP graph capture, tight
+ * loops, harnesses that forbid hipMalloc): no counterpart in the reference.  The same two kernels as
+ * cfd_total_density, queued on the handle's stream; the sum is written to d_out, ONE double in DEVICE
+ * memory owned by the caller, complete once the stream has run (nothing is copied to the host, the
+ * stream is not synchronised).  The block partials live in a fixed array inside the library's code
+ * object (1024 doubles = 8 KiB per GPU, held until the process ends) instead of allocated memory, and the
+ * call itself calls no hipMalloc / hipFree or any allocating routine.  Same launch geometry as
+ * cfd_total_density, hence the same bits.  Limits: at most CFD_NOALLOC_MAX_CELLS owned cells
+ * (CFD_E_ARG beyond); every call on one GPU uses that GPU's one array, so two calls that overlap in time
+ * on the same GPU (different handles on different streams) race -- order them. */
+#define CFD_NOALLOC_MAX_CELLS 2147483648L
+int cfd_total_density_noalloc(cfd_handle *h, double *d_out);
+
 /* Copies one time slot to the host.  slot_rel: 0 = currModTime, 1 = one back, 2 = two back
  * (pushBackTime, src/SolutionDomain.hs:422-423).  out[i] receives nx*ny*nz doubles. */
 int cfd_read_fields(cfd_handle *h, int slot_rel, double *const out[CFD_NPROP]);
