@@ -1265,9 +1265,9 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     };
 
     auto row = [&](int j, double* Rw, const double* Rc, const double* Re, bool first) {
-        double h[3][NF3];
+        double hx[NF3];
 #pragma unroll
-        for (int f = 0; f < NF3; ++f) h[0][f] = half_slope(Re[f], Rc[f], Rw[f]);
+        for (int f = 0; f < NF3; ++f) hx[f] = half_slope(Re[f], Rc[f], Rw[f]);
         load_row(clampx(j + RD - 1), Rw);
         const unsigned char act_n = load_act(clampx(j + 1));
         double pp[NF3];
@@ -1277,13 +1277,16 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
 #pragma unroll
             for (int f = 0; f < NF3; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
         }
-#pragma unroll
-        for (int f = 0; f < NF3; ++f) {
-            h[1][f] = half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS]);
-            h[2][f] = half_slope(lraw[f * NT + lT], Rc[f], lraw[f * NT + lB]);
-        }
         StreamA3 A;
-        phaseA3s(K, Rc, h, mask_of(act_j != 0), A);
+        // the y and z slopes are formed when their direction's turn comes (the neighbours' values are read
+        // from LDS then), which keeps the registers a direction needs from piling up in front of the first one
+        phaseA3s_by_direction(K, Rc, [&](int d, double hd[NF3]) {
+#pragma unroll
+            for (int f = 0; f < NF3; ++f)
+                hd[f] = d == 0 ? hx[f]
+                      : d == 1 ? half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS])
+                               : half_slope(lraw[f * NT + lT], Rc[f], lraw[f * NT + lB]);
+        }, mask_of(act_j != 0), A);
         if (first) {    // clamp-to-self on the West side (kept a real branch by the empty asm)
             asm volatile("");
             mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwp[3] = A.mw[3]; mwpD = A.me[S3_DYE];

@@ -428,6 +428,7 @@ CFD_HD void phaseB2(const SweepConsts& k, const PhaseA2& C, const ShareX2& XE, c
 // ------------------------------------------------------------------------------------------
 struct FastConsts {
     double rcx, rcy, rcz;   // dt/dx, dt/dy, dt/dz           (flux divergence per unit volume)
+    double rcx2, rcy2, rcz2;    // 2 dt/dx, ...             (streaming forms: face differences come out halved)
     double kxx, kyy, kzz;   // dt/dx^2, dt/dy^2, dt/dz^2
     double kxy, kxz, kyz;   // dt/(2 dx dy), dt/(2 dx dz), dt/(2 dy dz)
     double kxxm, kyym, kzzm;    // (2 + m23) * kxx, ...
@@ -448,6 +449,7 @@ struct FastConsts {
 inline FastConsts make_fast_consts(const SweepConsts& c, double dx, double dy, double dz = 1.0) {
     FastConsts f;
     f.rcx = c.dt / dx;  f.rcy = c.dt / dy;  f.rcz = c.dt / dz;
+    f.rcx2 = 2.0 * f.rcx;  f.rcy2 = 2.0 * f.rcy;  f.rcz2 = 2.0 * f.rcz;
     f.kxx = c.dt / (dx * dx);  f.kyy = c.dt / (dy * dy);  f.kzz = c.dt / (dz * dz);
     f.kxy = c.dt / (2.0 * dx * dy);  f.kxz = c.dt / (2.0 * dx * dz);  f.kyz = c.dt / (2.0 * dy * dz);
     f.kxxm = (2.0 + c.m23) * f.kxx;  f.kyym = (2.0 + c.m23) * f.kyy;  f.kzzm = (2.0 + c.m23) * f.kzz;
@@ -633,40 +635,67 @@ struct StreamA2 {
     double mn[2];       // message to the North neighbour: U, V (its T and Dye entries equal ms's)
 };
 
+// Face differences without face values.  With the two limited states of a direction written as c + h and
+// c - h (h = the half-slope), every upper-minus-lower difference of a product of them has a closed form
+// with no cancellation:
+//     (r+hr)(u+hu)         - (r-hr)(u-hu)         = 2 B,                B = r hu + hr u
+//     (r+hr)(u+hu)(x+hx)   - (r-hr)(u-hu)(x-hx)   = 2 (B x + A hx),     A = r u + hr hu
+//     mu+ (x+hx)           - mu- (x-hx)           = D x + S hx,         S = mu+ + mu-,  D = mu+ - mu-
+//     mu+ (u+hu)(v+hv)     - mu- (u-hu)(v-hv)     = D (u v + hu hv) + S (u hv + hu v)
+// (the factor 2 rides on the direction's constant).  Fewer operations than forming both face products and
+// subtracting them, and no face value of Density, Dye or a velocity component is ever formed.  The
+// exact-cancellation rule holds term by term: zero half-slopes give B = 0, D = 0 and exact zeros
+// throughout, and a field that is identically zero (x = hx = 0) contributes exact zeros.
+struct FluxDir {
+    double A, B, dP, S, D;
+};
+// r, t: Density and Temperature of the cell, hr, ht: their half-slopes; u, hu: the velocity component normal
+// to the faces.  dP = upper-minus-lower difference of T rho, halved.
+CFD_HD FluxDir flux_dir(const FastConsts& k, double r, double hr, double t, double ht, double u, double hu) {
+    FluxDir f;
+    f.A = fma(hr, hu, r * u);
+    f.B = fma(r, hu, hr * u);
+    f.dP = fma(t, hr, r * ht);
+    const double mU = mu_stream(k, t + ht), mL = mu_stream(k, t - ht);
+    f.S = mU + mL;
+    f.D = mU - mL;
+    return f;
+}
+// half the upper-minus-lower difference of (rho u_normal x) over the direction's two faces
+CFD_HD double flux_of(const FluxDir& f, double x, double hx) { return fma(f.B, x, f.A * hx); }
+// upper-minus-lower difference of mu_f x_f
+CFD_HD double visc_of(const FluxDir& f, double x, double hx) { return fma(f.D, x, f.S * hx); }
+// upper-minus-lower difference of (mu_f u_f) v_f - mu_f u_f - v_f; dmu_u = visc_of(f, u, hu)
+CFD_HD double paired_of(const FluxDir& f, double u, double hu, double v, double hv, double dmu_u) {
+    const double p1 = fma(hu, hv, u * v), p2 = fma(hu, v, u * hv);
+    return fma(-2.0, hv, fma(f.S, p2, f.D * p1) - dmu_u);
+}
+
 template <class S = SelMask>
 CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[NF2],
                      const double n[NF2], const double s[NF2], typename S::mask act, StreamA2& o) {
-    // ---- x faces
-    double fE[NF2], fW[NF2];
-    for (int q = 0; q < NF2; ++q) { fE[q] = c[q] + hx[q]; fW[q] = c[q] - hx[q]; }
-    const double muE = mu_stream(k, fE[F2_T]), muW = mu_stream(k, fW[F2_T]);
-    // pressure p = R (T rho): the face difference is taken on T rho and scaled by R once
-    const double pE = fE[F2_T] * fE[F2_RHO], pW = fW[F2_T] * fW[F2_RHO];
-    const double mE = fE[F2_RHO] * fE[F2_U], mW = fW[F2_RHO] * fW[F2_U];
+    const double rho = c[F2_RHO], T = c[F2_T];
     double div[5];
-    div[E2_RHO] = k.rcx * (mE - mW);
-    div[E2_U] = k.rcx * fma(k.R, pE - pW, mE * fE[F2_U] - mW * fW[F2_U]);
-    div[E2_V] = k.rcx * (mE * fE[F2_V] - mW * fW[F2_V]);
-    div[E2_T] = k.rcx * (mE * fE[F2_T] - mW * fW[F2_T]);       // cv m T + p u = (cv + R) m T: times cp below, once
-    div[E2_DYE] = k.rcx * (mE * fE[F2_DYE] - mW * fW[F2_DYE]);
-    const double dea = muE * fE[F2_U] - muW * fW[F2_U], deb = muE * fE[F2_V] - muW * fW[F2_V];
+    // ---- x faces (pressure p = R (T rho): the face difference is taken on T rho and scaled by R once;
+    // energy flux cv m T + p u = (cv + R) m T: times cp below, once)
+    const FluxDir X = flux_dir(k, rho, hx[F2_RHO], T, hx[F2_T], c[F2_U], hx[F2_U]);
+    div[E2_RHO] = k.rcx2 * X.B;
+    div[E2_U] = k.rcx2 * fma(k.R, X.dP, flux_of(X, c[F2_U], hx[F2_U]));
+    div[E2_V] = k.rcx2 * flux_of(X, c[F2_V], hx[F2_V]);
+    div[E2_T] = k.rcx2 * flux_of(X, T, hx[F2_T]);
+    div[E2_DYE] = k.rcx2 * flux_of(X, c[F2_DYE], hx[F2_DYE]);
+    const double dea = visc_of(X, c[F2_U], hx[F2_U]), deb = visc_of(X, c[F2_V], hx[F2_V]);
     // ---- y faces
-    double fN[NF2], fS[NF2];
-    for (int q = 0; q < NF2; ++q) {
-        const double hy = half_slope(n[q], c[q], s[q]);
-        fN[q] = c[q] + hy; fS[q] = c[q] - hy;
-    }
-    const double muN = mu_stream(k, fN[F2_T]), muS = mu_stream(k, fS[F2_T]);
-    const double pN = fN[F2_T] * fN[F2_RHO], pS = fS[F2_T] * fS[F2_RHO];
-    const double mN = fN[F2_RHO] * fN[F2_V], mS = fS[F2_RHO] * fS[F2_V];
-    div[E2_RHO] = fma(k.rcy, mN - mS, div[E2_RHO]);
-    div[E2_U] = fma(k.rcy, mN * fN[F2_U] - mS * fS[F2_U], div[E2_U]);
-    div[E2_V] = fma(k.rcy, fma(k.R, pN - pS, mN * fN[F2_V] - mS * fS[F2_V]), div[E2_V]);
-    div[E2_T] = fma(k.rcy, mN * fN[F2_T] - mS * fS[F2_T], div[E2_T]);
-    div[E2_DYE] = fma(k.rcy, mN * fN[F2_DYE] - mS * fS[F2_DYE], div[E2_DYE]);
-    const double aN = muN * fN[F2_U], aS = muS * fS[F2_U];
-    const double dna = aN - aS, dnb = muN * fN[F2_V] - muS * fS[F2_V];
-    const double qq = ((aN * fN[F2_V] - aS * fS[F2_V]) - dna) - (fN[F2_V] - fS[F2_V]);
+    double hy[NF2];
+    for (int q = 0; q < NF2; ++q) hy[q] = half_slope(n[q], c[q], s[q]);
+    const FluxDir Y = flux_dir(k, rho, hy[F2_RHO], T, hy[F2_T], c[F2_V], hy[F2_V]);
+    div[E2_RHO] = fma(k.rcy2, Y.B, div[E2_RHO]);
+    div[E2_U] = fma(k.rcy2, flux_of(Y, c[F2_U], hy[F2_U]), div[E2_U]);
+    div[E2_V] = fma(k.rcy2, fma(k.R, Y.dP, flux_of(Y, c[F2_V], hy[F2_V])), div[E2_V]);
+    div[E2_T] = fma(k.rcy2, flux_of(Y, T, hy[F2_T]), div[E2_T]);
+    div[E2_DYE] = fma(k.rcy2, flux_of(Y, c[F2_DYE], hy[F2_DYE]), div[E2_DYE]);
+    const double dna = visc_of(Y, c[F2_U], hy[F2_U]), dnb = visc_of(Y, c[F2_V], hy[F2_V]);
+    const double qq = paired_of(Y, c[F2_U], hy[F2_U], c[F2_V], hy[F2_V], dna);
     // ---- centre products
     const double muC = mu_stream(k, c[F2_T]);
     const double a = muC * c[F2_U], b = muC * c[F2_V], g = muC * c[F2_DYE];
@@ -1128,35 +1157,36 @@ struct StreamA3 {
     double mt[4];       // message to the Top neighbour: U, V, W, T (Dye entry equals mb's)
 };
 
-CFD_HD void phaseA3s(const FastConsts& k, const double c[NF3], const double h[3][NF3], lane_mask act, StreamA3& o) {
-    const double rc[3] = {k.rcx, k.rcy, k.rcz};
+// slopes(d, hd): fills hd[NF3] with the limited half-slopes of the six stored values along direction d; it is
+// called once per direction, in the order 0, 1, 2, right before that direction's faces are worked on, so that a
+// kernel can fetch its neighbours' values late and nothing of a direction outlives it but its sums.
+template <class SlopeFn>
+CFD_HD void phaseA3s_by_direction(const FastConsts& k, const double c[NF3], SlopeFn&& slopes, lane_mask act, StreamA3& o) {
+    const double rc2[3] = {k.rcx2, k.rcy2, k.rcz2};
+    const double rho = c[F3_RHO], T = c[F3_T];
     double div[NE3] = {0, 0, 0, 0, 0, 0};
     double dmu[3][3];       // dmu[d][q] = mu_f (u_q)_f on the upper face of direction d minus the lower face
     double pair[3];         // pair[0] = X-neighbours' Y-face term, [1] = X-neighbours' Z-face term, [2] = Z-neighbours' Y-face term
     for (int d = 0; d < 3; ++d) {
-        double fu[NF3], fl[NF3];
-        for (int q = 0; q < NF3; ++q) { fu[q] = c[q] + h[d][q]; fl[q] = c[q] - h[d][q]; }
-        const double muU = mu_stream(k, fu[F3_T]), muL = mu_stream(k, fl[F3_T]);
-        const double pU = fu[F3_T] * fu[F3_RHO], pL = fl[F3_T] * fl[F3_RHO];       // p / R; scaled once below
-        const double mU = fu[F3_RHO] * fu[F3_U + d], mL = fl[F3_RHO] * fl[F3_U + d];
-        // flux differences across direction d (products rounded, then subtracted)
-        div[E3_RHO] = fma(rc[d], mU - mL, div[E3_RHO]);
+        double h[NF3];
+        slopes(d, h);
+        const FluxDir F = flux_dir(k, rho, h[F3_RHO], T, h[F3_T], c[F3_U + d], h[F3_U + d]);
+        // flux differences across direction d (see flux_dir: halved, no face values)
+        div[E3_RHO] = fma(rc2[d], F.B, div[E3_RHO]);
         for (int cc = 0; cc < 3; ++cc) {
-            double dd = mU * fu[F3_U + cc] - mL * fl[F3_U + cc];
-            if (cc == d) dd = fma(k.R, pU - pL, dd);
-            div[E3_U + cc] = fma(rc[d], dd, div[E3_U + cc]);
+            double dd = flux_of(F, c[F3_U + cc], h[F3_U + cc]);
+            if (cc == d) dd = fma(k.R, F.dP, dd);
+            div[E3_U + cc] = fma(rc2[d], dd, div[E3_U + cc]);
         }
-        div[E3_T] = fma(rc[d], mU * fu[F3_T] - mL * fl[F3_T], div[E3_T]);     // cv m T + p u = (cv + R) m T: times cp below, once
-        div[E3_DYE] = fma(rc[d], mU * fu[F3_DYE] - mL * fl[F3_DYE], div[E3_DYE]);
-        double au[3], al[3];
-        for (int q = 0; q < 3; ++q) { au[q] = muU * fu[F3_U + q]; al[q] = muL * fl[F3_U + q]; dmu[d][q] = au[q] - al[q]; }
+        div[E3_T] = fma(rc2[d], flux_of(F, T, h[F3_T]), div[E3_T]);       // cv m T + p u = (cv + R) m T: times cp below, once
+        div[E3_DYE] = fma(rc2[d], flux_of(F, c[F3_DYE], h[F3_DYE]), div[E3_DYE]);
+        for (int q = 0; q < 3; ++q) dmu[d][q] = visc_of(F, c[F3_U + q], h[F3_U + q]);
         // paired terms: difference over the faces of d of (mu u_a) u_b - mu u_a - u_b
         if (d == 1) {
-            pair[0] = ((au[0] * fu[F3_V] - al[0] * fl[F3_V]) - dmu[1][0]) - (fu[F3_V] - fl[F3_V]);     // [Mew,U][V] X Y
-            pair[2] = ((au[2] * fu[F3_V] - al[2] * fl[F3_V]) - dmu[1][2]) - (fu[F3_V] - fl[F3_V]);     // [Mew,W][V] Z Y
+            pair[0] = paired_of(F, c[F3_U], h[F3_U], c[F3_V], h[F3_V], dmu[1][0]);     // [Mew,U][V] X Y
+            pair[2] = paired_of(F, c[F3_W], h[F3_W], c[F3_V], h[F3_V], dmu[1][2]);     // [Mew,W][V] Z Y
         }
-        if (d == 2)
-            pair[1] = ((au[0] * fu[F3_W] - al[0] * fl[F3_W]) - dmu[2][0]) - (fu[F3_W] - fl[F3_W]);     // [Mew,U][W] X Z
+        if (d == 2) pair[1] = paired_of(F, c[F3_U], h[F3_U], c[F3_W], h[F3_W], dmu[2][0]);     // [Mew,U][W] X Z
     }
     // ---- centre products
     const double muC = mu_stream(k, c[F3_T]);
@@ -1214,6 +1244,10 @@ CFD_HD void phaseA3s(const FastConsts& k, const double c[NF3], const double h[3]
     o.q[S3_T] = fma(-o.coef[S3_T], gT, c[F3_T]);
     o.q[S3_DYE] = fma(-o.coef[S3_DYE], gD, c[F3_DYE]);
     o.rho = c[F3_RHO] - div[E3_RHO];
+}
+
+CFD_HD void phaseA3s(const FastConsts& k, const double c[NF3], const double h[3][NF3], lane_mask act, StreamA3& o) {
+    phaseA3s_by_direction(k, c, [&](int d, double hd[NF3]) { for (int q = 0; q < NF3; ++q) hd[q] = h[d][q]; }, act, o);
 }
 
 // q += coef * (message from the West neighbour); mwD: that message's Dye entry
