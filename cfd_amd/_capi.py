@@ -13,11 +13,15 @@ LIB_PATH = os.environ.get("CFD_LIB") or os.path.join(_HERE, "libcfdhip.so")
 CFD_NPROP = 7
 CFD_OK, CFD_E_ARG, CFD_E_DEVICE, CFD_E_MEMORY, CFD_E_STATE = 0, -1, -2, -3, -4
 CFD_FLAG_DEFAULT, CFD_FLAG_SIMPLE_KERNEL, CFD_FLAG_FORCE_3D, CFD_FLAG_FAST_MATH = 0, 1, 2, 4
+CFD_TRANSPORT_COPY, CFD_TRANSPORT_RCCL = 0, 1
+CFD_COMM_ID_BYTES = 128
 
 # every symbol include/cfd_hip.h declares
 EXPORTS = [
     "cfd_default_params", "cfd_create", "cfd_destroy", "cfd_step", "cfd_sweep", "cfd_sweep_and_filter", "cfd_sweep_begin", "cfd_sweep_end", "cfd_sweep_begin_depth", "cfd_sweep_end_on", "cfd_sweep_pair_and_filter", "cfd_time_filter",
     "cfd_total_density", "cfd_total_density_noalloc", "cfd_read_fields", "cfd_write_fields", "cfd_set_time", "cfd_property_slice", "cfd_time", "cfd_last_error", "cfd_halo_planes", "cfd_halo_planes_depth", "cfd_set_ghost_active", "cfd_pair_available",
+    "cfd_multi_create", "cfd_multi_create_rank", "cfd_comm_unique_id", "cfd_multi_destroy", "cfd_multi_step", "cfd_multi_total_density",
+    "cfd_multi_read_fields", "cfd_multi_time", "cfd_multi_sync", "cfd_multi_info", "cfd_multi_slab", "cfd_rccl_selftest",
     "cfd_stream", "cfd_set_stream", "cfd_kernel_name", "cfd_sync", "cfd_set_timing", "cfd_sweep_timing", "cfd_kernel_timing", "cfd_live_fields",
 ]
 
@@ -96,8 +100,24 @@ def load():
     L.cfd_kernel_timing.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                     ctypes.c_int]
     L.cfd_live_fields.argtypes = [H, ctypes.POINTER(ctypes.c_int)]
+    PI = ctypes.POINTER(ctypes.c_int)
+    L.cfd_multi_create.argtypes = [ctypes.POINTER(CfdParams), ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, PP,
+                                   ctypes.c_void_p, ctypes.POINTER(H)]
+    L.cfd_comm_unique_id.argtypes = [ctypes.c_void_p]
+    L.cfd_multi_create_rank.argtypes = [ctypes.POINTER(CfdParams), ctypes.c_int, ctypes.c_int, ctypes.c_void_p, PP,
+                                        ctypes.c_void_p, ctypes.POINTER(H)]
+    L.cfd_multi_destroy.argtypes = [H]
+    L.cfd_multi_destroy.restype = None
+    L.cfd_multi_step.argtypes = [H, ctypes.c_int]
+    L.cfd_multi_total_density.argtypes = [H, ctypes.POINTER(ctypes.c_double)]
+    L.cfd_multi_read_fields.argtypes = [H, ctypes.c_int, PP]
+    L.cfd_multi_time.argtypes = [H, PI, PI]
+    L.cfd_multi_sync.argtypes = [H]
+    L.cfd_multi_info.argtypes = [H, PI, PI, PI]
+    L.cfd_multi_slab.argtypes = [H, ctypes.c_int, ctypes.POINTER(H), PI, PI]
+    L.cfd_rccl_selftest.argtypes = [ctypes.c_int, ctypes.c_size_t]
     for name in EXPORTS:
-        if name not in ("cfd_destroy", "cfd_last_error", "cfd_kernel_name"):
+        if name not in ("cfd_destroy", "cfd_multi_destroy", "cfd_last_error", "cfd_kernel_name"):
             getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L

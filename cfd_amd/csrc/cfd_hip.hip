@@ -39,6 +39,9 @@ static int fail(int code, const std::string& msg) {
     return code;
 }
 
+// for the library's other translation unit (cfd_multi.hip): records the message cfd_last_error returns
+extern "C" int cfd_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \

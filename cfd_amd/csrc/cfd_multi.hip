@@ -1,0 +1,588 @@
+// Several slabs behind one handle: the x-slab decomposition of the field update driven from C, on top of the
+// single-slab entry points of cfd_hip.hip (cfd_create, cfd_sweep_begin_depth / cfd_sweep_end_on,
+// cfd_halo_planes_depth, cfd_sweep_pair_and_filter, cfd_total_density_noalloc).
+//
+// Two ways to own the slabs:
+//   * cfd_multi_create       one host thread, all slabs of the grid in this process: one slab per listed device
+//                            (RCCL transport, ncclCommInitAll) or any number of slabs per device (copy
+//                            transport: device-to-device / peer copies; several "virtual" slabs on one GPU);
+//   * cfd_multi_create_rank  one process per GPU (this process holds slab `rank` of `world`): RCCL transport
+//                            with a communicator built from a broadcast ncclUniqueId (ncclCommInitRank).
+// Transport = who moves the ghost planes: RCCL over xGMI (grouped ncclSend / ncclRecv between x-neighbours,
+// ncclAllReduce for the density sum) or plain copies.  A plane of all live fields is one contiguous run in a
+// time slot, so a halo is ONE message per neighbour with no pack kernel.
+//
+// Streams: per device one compute stream and one high-priority side stream, shared by every slab on that
+// device (several virtual slabs on one GPU therefore never hold more than two streams).  A step with the
+// one-pass tail hides both of its exchanges behind the first sweep's interior planes:
+//     side:  wait(previous step) -> exchange 1 plane -> edge planes of sweep 1 -> exchange 2 planes -> event
+//     main:  interior planes of sweep 1 ....................................... wait(event) -> sweeps 2+3+filter
+// Every cross-stream wait is on an event recorded BEFORE the wait is queued, by work that is already queued.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cfd_hip.h"
+
+extern "C" int cfd_internal_fail(int code, const char* msg);     // cfd_hip.hip: sets cfd_last_error's text
+
+namespace {
+
+int fail(int code, const std::string& m) { return cfd_internal_fail(code, m.c_str()); }
+
+#define M_HIP(expr)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(CFD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define M_NCCL(expr)                                                                             \
+    do {                                                                                         \
+        ncclResult_t r_ = (expr);                                                                \
+        if (r_ != ncclSuccess) return fail(CFD_E_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+#define M_CFD(expr)                                                                              \
+    do {                                                                                         \
+        int rc_ = (expr);                                                                        \
+        if (rc_ != CFD_OK) return rc_;                                                           \
+    } while (0)
+
+struct DeviceStreams {
+    int device;
+    hipStream_t main, side;
+};
+
+struct Slab {
+    cfd_handle* h = nullptr;
+    int rank = 0;               // position of the slab along x (0 = lowest planes)
+    int device = 0;
+    int x0 = 0, x1 = 0;         // global plane range [x0, x1)
+    int ds = 0;                 // index into cfd_multi::streams
+    ncclComm_t comm = nullptr;
+    hipEvent_t done = nullptr;  // recorded on the compute stream when the slab's current slot is complete
+    hipEvent_t edge = nullptr;  // recorded on the side stream when the edge planes of a split sweep are complete
+    hipEvent_t side_done = nullptr;     // recorded on the side stream at the end of a step's boundary work
+    double* d_sum = nullptr;    // one double: this slab's density sum, all-reduced in place
+};
+
+}  // namespace
+
+struct cfd_multi {
+    cfd_params p;               // the GLOBAL grid (nx = all planes)
+    int world = 1;              // slabs along x, in all processes
+    int transport = CFD_TRANSPORT_COPY;
+    bool pair = false;          // the step's tail runs as one pass on every slab
+    bool overlap = true;
+    size_t plane = 0;
+    std::vector<Slab> slab;     // the slabs this process holds, in rank order
+    std::vector<DeviceStreams> streams;
+    int cmt = 0, cat = 0;
+};
+
+namespace {
+
+hipStream_t main_of(const cfd_multi* m, const Slab& s) { return m->streams[s.ds].main; }
+hipStream_t side_of(const cfd_multi* m, const Slab& s) { return m->streams[s.ds].side; }
+
+// Ghost-plane exchange `depth` planes deep between x-neighbours, queued on the side (on_side) or compute stream
+// of every slab.  Copy transport: the receiver pulls from its neighbour's send planes once `ready` of that
+// neighbour (its event saying those planes are complete) has fired.  RCCL: one group of sends and receives; a
+// rank's own stream order covers its send planes, the rendezvous covers the neighbour's.
+enum Ready { READY_DONE, READY_EDGE };
+
+int exchange(cfd_multi* m, int depth, bool on_side, Ready ready) {
+    if (m->world == 1) return CFD_OK;
+    struct Planes { void *slo, *shi, *rlo, *rhi; size_t bytes; };
+    std::vector<Planes> pl(m->slab.size());
+    for (size_t i = 0; i < m->slab.size(); ++i)
+        M_CFD(cfd_halo_planes_depth(m->slab[i].h, depth, &pl[i].slo, &pl[i].shi, &pl[i].rlo, &pl[i].rhi, &pl[i].bytes));
+    if (m->transport == CFD_TRANSPORT_RCCL) {
+        M_NCCL(ncclGroupStart());
+        for (size_t i = 0; i < m->slab.size(); ++i) {
+            const Slab& s = m->slab[i];
+            hipStream_t st = on_side ? side_of(m, s) : main_of(m, s);
+            const size_t count = pl[i].bytes / sizeof(double);
+            if (s.rank > 0) {
+                M_NCCL(ncclSend(pl[i].slo, count, ncclDouble, s.rank - 1, s.comm, st));
+                M_NCCL(ncclRecv(pl[i].rlo, count, ncclDouble, s.rank - 1, s.comm, st));
+            }
+            if (s.rank < m->world - 1) {
+                M_NCCL(ncclSend(pl[i].shi, count, ncclDouble, s.rank + 1, s.comm, st));
+                M_NCCL(ncclRecv(pl[i].rhi, count, ncclDouble, s.rank + 1, s.comm, st));
+            }
+        }
+        M_NCCL(ncclGroupEnd());
+        return CFD_OK;
+    }
+    for (size_t i = 0; i < m->slab.size(); ++i) {
+        const Slab& s = m->slab[i];
+        M_HIP(hipSetDevice(s.device));
+        hipStream_t st = on_side ? side_of(m, s) : main_of(m, s);
+        for (int side = 0; side < 2; ++side) {
+            const int nb_rank = side == 0 ? s.rank - 1 : s.rank + 1;
+            if (nb_rank < 0 || nb_rank >= m->world) continue;
+            const size_t k = i + (side == 0 ? -1 : 1);          // all slabs are local with the copy transport
+            const Slab& nb = m->slab[k];
+            M_HIP(hipStreamWaitEvent(st, ready == READY_EDGE ? nb.edge : nb.done, 0));
+            void* dst = side == 0 ? pl[i].rlo : pl[i].rhi;
+            const void* src = side == 0 ? pl[k].shi : pl[k].slo;
+            if (nb.device == s.device)
+                M_HIP(hipMemcpyAsync(dst, src, pl[i].bytes, hipMemcpyDeviceToDevice, st));
+            else
+                M_HIP(hipMemcpyPeerAsync(dst, s.device, src, nb.device, pl[i].bytes, st));
+        }
+    }
+    return CFD_OK;
+}
+
+int record(cfd_multi* m, bool edge_event) {
+    for (Slab& s : m->slab) {
+        M_HIP(hipSetDevice(s.device));
+        if (edge_event) M_HIP(hipEventRecord(s.edge, side_of(m, s)));
+        else M_HIP(hipEventRecord(s.done, main_of(m, s)));
+    }
+    return CFD_OK;
+}
+
+// One sweep of every slab with its one-plane exchange on the compute stream: exchange, interior, edge.
+int sweep_all(cfd_multi* m, int step_time, int with_filter) {
+    if (m->world == 1) {
+        for (Slab& s : m->slab) M_CFD(with_filter ? cfd_sweep_and_filter(s.h) : cfd_sweep(s.h, step_time));
+        return record(m, false);
+    }
+    M_CFD(exchange(m, 1, false, READY_DONE));
+    for (Slab& s : m->slab) M_CFD(cfd_sweep_begin_depth(s.h, step_time, with_filter, 1));
+    for (Slab& s : m->slab) M_CFD(cfd_sweep_end(s.h));
+    return record(m, false);
+}
+
+int step_once(cfd_multi* m) {
+    if (m->world == 1) {
+        for (Slab& s : m->slab) M_CFD(cfd_step(s.h, 1));
+        M_CFD(record(m, false));
+    } else if (!m->pair) {
+        M_CFD(sweep_all(m, 1, 0));
+        M_CFD(sweep_all(m, 0, 0));
+        M_CFD(sweep_all(m, 0, 1));
+    } else if (!m->overlap) {
+        M_CFD(sweep_all(m, 1, 0));
+        M_CFD(exchange(m, 2, false, READY_DONE));
+        for (Slab& s : m->slab) M_CFD(cfd_sweep_pair_and_filter(s.h));
+        M_CFD(record(m, false));
+    } else {
+        // boundary work of the step on the side stream, beside the interior planes of the first sweep
+        for (Slab& s : m->slab) {
+            M_HIP(hipSetDevice(s.device));
+            M_HIP(hipStreamWaitEvent(side_of(m, s), s.done, 0));    // the previous step of this slab
+        }
+        M_CFD(exchange(m, 1, true, READY_DONE));
+        for (Slab& s : m->slab) M_CFD(cfd_sweep_begin_depth(s.h, 1, 0, 2));       // compute stream: interior
+        for (Slab& s : m->slab) M_CFD(cfd_sweep_end_on(s.h, (void*)side_of(m, s)));  // side stream: two planes per side
+        M_CFD(record(m, true));
+        M_CFD(exchange(m, 2, true, READY_EDGE));
+        for (Slab& s : m->slab) {
+            M_HIP(hipSetDevice(s.device));
+            M_HIP(hipEventRecord(s.side_done, side_of(m, s)));
+            M_HIP(hipStreamWaitEvent(main_of(m, s), s.side_done, 0));
+        }
+        for (Slab& s : m->slab) M_CFD(cfd_sweep_pair_and_filter(s.h));
+        M_CFD(record(m, false));
+    }
+    m->cmt = (m->cmt + 1) % 3;
+    m->cat += 1;
+    return CFD_OK;
+}
+
+int streams_for(cfd_multi* m, int device, int* index) {
+    for (size_t i = 0; i < m->streams.size(); ++i)
+        if (m->streams[i].device == device) { *index = (int)i; return CFD_OK; }
+    DeviceStreams d{device, nullptr, nullptr};
+    M_HIP(hipSetDevice(device));
+    int lo = 0, hi = 0;
+    M_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));       // hi = the numerically lowest value = highest priority
+    M_HIP(hipStreamCreateWithFlags(&d.main, hipStreamNonBlocking));
+    M_HIP(hipStreamCreateWithPriority(&d.side, hipStreamNonBlocking, hi));
+    m->streams.push_back(d);
+    *index = (int)m->streams.size() - 1;
+    return CFD_OK;
+}
+
+// Creates the slab `s` (rank, device, x0, x1 set) from the slab's own fields / mask (owned planes only).
+int make_slab(cfd_multi* m, Slab& s, const double* const fields[CFD_NPROP], const uint8_t* active, int extra_flags) {
+    cfd_params q = m->p;
+    q.nx = s.x1 - s.x0;
+    q.device = s.device;
+    q.flags = m->p.flags | extra_flags;
+    q.ghost_lo = s.rank > 0;
+    q.ghost_hi = s.rank < m->world - 1;
+    M_CFD(cfd_create(&q, fields, active, &s.h));
+    M_CFD(streams_for(m, s.device, &s.ds));
+    M_CFD(cfd_set_stream(s.h, (void*)main_of(m, s)));
+    M_HIP(hipSetDevice(s.device));
+    M_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    M_HIP(hipEventCreateWithFlags(&s.edge, hipEventDisableTiming));
+    M_HIP(hipEventCreateWithFlags(&s.side_done, hipEventDisableTiming));
+    M_HIP(hipMalloc((void**)&s.d_sum, sizeof(double)));
+    M_HIP(hipEventRecord(s.done, main_of(m, s)));
+    return CFD_OK;
+}
+
+bool w_identically_zero(const double* w, size_t n) {
+    const uint64_t* b = reinterpret_cast<const uint64_t*>(w);
+    for (size_t i = 0; i < n; ++i)
+        if (b[i] != 0) return false;
+    return true;
+}
+
+bool env_flag(const char* name, bool dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) != 0 : dflt;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cfd_multi_destroy(cfd_multi* m) {
+    if (!m) return;
+    for (Slab& s : m->slab) {
+        (void)hipSetDevice(s.device);
+        if (s.h) { (void)cfd_sync(s.h); }
+    }
+    for (DeviceStreams& d : m->streams) {
+        (void)hipSetDevice(d.device);
+        if (d.side) (void)hipStreamSynchronize(d.side);
+        if (d.main) (void)hipStreamSynchronize(d.main);
+    }
+    for (Slab& s : m->slab) {
+        (void)hipSetDevice(s.device);
+        if (s.comm) (void)ncclCommDestroy(s.comm);
+        if (s.h) cfd_destroy(s.h);          // the handle does not own the streams it was pointed at
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.edge) (void)hipEventDestroy(s.edge);
+        if (s.side_done) (void)hipEventDestroy(s.side_done);
+        if (s.d_sum) (void)hipFree(s.d_sum);
+    }
+    for (DeviceStreams& d : m->streams) {
+        (void)hipSetDevice(d.device);
+        if (d.side) (void)hipStreamDestroy(d.side);
+        if (d.main) (void)hipStreamDestroy(d.main);
+    }
+    delete m;
+}
+
+int cfd_multi_create(const cfd_params* p, int n_slabs, const int32_t* devices, int transport,
+                     const double* const fields[CFD_NPROP], const uint8_t* active, cfd_multi** out) {
+    if (!p || !fields || !active || !out) return fail(CFD_E_ARG, "cfd_multi_create: null pointer");
+    *out = nullptr;
+    if (n_slabs < 1) return fail(CFD_E_ARG, "cfd_multi_create: n_slabs must be >= 1");
+    if (p->nx < n_slabs) return fail(CFD_E_ARG, "cfd_multi_create: fewer x-planes than slabs");
+    if (transport != CFD_TRANSPORT_COPY && transport != CFD_TRANSPORT_RCCL)
+        return fail(CFD_E_ARG, "cfd_multi_create: transport must be CFD_TRANSPORT_COPY or CFD_TRANSPORT_RCCL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(CFD_E_DEVICE, "cfd_multi_create: no HIP device available (this library has no CPU path)");
+    std::vector<int> dev(n_slabs);
+    for (int i = 0; i < n_slabs; ++i) {
+        dev[i] = devices ? devices[i] : i % ndev;
+        if (dev[i] < 0 || dev[i] >= ndev) return fail(CFD_E_ARG, "cfd_multi_create: device ordinal out of range");
+    }
+    if (transport == CFD_TRANSPORT_RCCL)
+        for (int i = 0; i < n_slabs; ++i)
+            for (int k = 0; k < i; ++k)
+                if (dev[i] == dev[k])
+                    return fail(CFD_E_ARG, "cfd_multi_create: the RCCL transport takes one slab per device (several slabs on "
+                                           "one device: CFD_TRANSPORT_COPY)");
+    cfd_multi* m = new cfd_multi();
+    m->p = *p;
+    m->world = n_slabs;
+    m->transport = transport;
+    m->plane = (size_t)p->ny * p->nz;
+    m->overlap = env_flag("CFD_MULTI_OVERLAP", true);
+    // The 2-D form (no W on the device) is a property of the WHOLE grid: a slab whose own W happens to be zero
+    // must not drop W while a neighbour keeps it (their planes would differ in size).
+    const bool two_d = p->nz == 1 && !(p->flags & CFD_FLAG_FORCE_3D) && w_identically_zero(fields[2], (size_t)p->nx * m->plane);
+    const int extra = two_d ? 0 : (p->nz == 1 ? CFD_FLAG_FORCE_3D : 0);
+    m->slab.resize(n_slabs);
+    int rc = CFD_OK;
+    for (int i = 0; i < n_slabs && rc == CFD_OK; ++i) {
+        Slab& s = m->slab[i];
+        s.rank = i;
+        s.device = dev[i];
+        s.x0 = (int)((long)p->nx * i / n_slabs);
+        s.x1 = (int)((long)p->nx * (i + 1) / n_slabs);
+        const double* f[CFD_NPROP];
+        for (int k = 0; k < CFD_NPROP; ++k) f[k] = fields[k] + (size_t)s.x0 * m->plane;
+        rc = make_slab(m, s, f, active + (size_t)s.x0 * m->plane, extra);
+    }
+    if (rc == CFD_OK && transport == CFD_TRANSPORT_RCCL && n_slabs > 1) {
+        std::vector<ncclComm_t> comms(n_slabs);
+        ncclResult_t r = ncclCommInitAll(comms.data(), n_slabs, dev.data());
+        if (r != ncclSuccess) rc = fail(CFD_E_DEVICE, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        else for (int i = 0; i < n_slabs; ++i) m->slab[i].comm = comms[i];
+    }
+    if (rc == CFD_OK && transport == CFD_TRANSPORT_COPY)
+        for (int i = 0; i + 1 < n_slabs && rc == CFD_OK; ++i)
+            if (dev[i] != dev[i + 1]) {
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, dev[i], dev[i + 1]);
+                if (can) {
+                    (void)hipSetDevice(dev[i]);     (void)hipDeviceEnablePeerAccess(dev[i + 1], 0);
+                    (void)hipSetDevice(dev[i + 1]); (void)hipDeviceEnablePeerAccess(dev[i], 0);
+                    (void)hipGetLastError();        // "already enabled" is fine
+                }
+            }
+    // every slab learns its neighbours' masks of the adjoining planes (the one-pass tail needs them), then the
+    // slabs agree on the form of a step
+    if (rc == CFD_OK && n_slabs > 1) {
+        bool pair = true;
+        for (int i = 0; i < n_slabs && rc == CFD_OK; ++i) {
+            const Slab& s = m->slab[i];
+            const uint8_t* lo = i > 0 ? active + (size_t)(s.x0 - 1) * m->plane : nullptr;
+            const uint8_t* hi = i < n_slabs - 1 ? active + (size_t)s.x1 * m->plane : nullptr;
+            rc = cfd_set_ghost_active(s.h, lo, hi);
+            int ok = 0;
+            if (rc == CFD_OK) rc = cfd_pair_available(s.h, &ok);
+            pair = pair && ok;
+        }
+        m->pair = pair && env_flag("CFD_MULTI_PAIR", true);
+    }
+    if (rc != CFD_OK) { cfd_multi_destroy(m); return rc; }
+    *out = m;
+    return CFD_OK;
+}
+
+int cfd_comm_unique_id(void* id128) {
+    if (!id128) return fail(CFD_E_ARG, "cfd_comm_unique_id: null pointer");
+    static_assert(sizeof(ncclUniqueId) == CFD_COMM_ID_BYTES, "ncclUniqueId is not 128 bytes");
+    ncclUniqueId id;
+    M_NCCL(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return CFD_OK;
+}
+
+int cfd_multi_create_rank(const cfd_params* p, int rank, int world, const void* id128,
+                          const double* const fields[CFD_NPROP], const uint8_t* active, cfd_multi** out) {
+    if (!p || !fields || !active || !out) return fail(CFD_E_ARG, "cfd_multi_create_rank: null pointer");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(CFD_E_ARG, "cfd_multi_create_rank: rank must be in [0, world)");
+    if (world > 1 && !id128) return fail(CFD_E_ARG, "cfd_multi_create_rank: a communicator id is needed for world > 1");
+    int dev = p->device;
+    if (dev < 0) M_HIP(hipGetDevice(&dev));
+    cfd_multi* m = new cfd_multi();
+    m->p = *p;                  // nx = this slab's planes; the global extent is not needed here
+    m->world = world;
+    m->transport = CFD_TRANSPORT_RCCL;
+    m->plane = (size_t)p->ny * p->nz;
+    m->overlap = env_flag("CFD_MULTI_OVERLAP", true);
+    m->slab.resize(1);
+    Slab& s = m->slab[0];
+    s.rank = rank;
+    s.device = dev;
+    s.x0 = 0;
+    s.x1 = p->nx;
+    int rc = CFD_OK;
+    hipStream_t st = nullptr;
+    int* d_flag = nullptr;
+    uint8_t *d_mlo = nullptr, *d_mhi = nullptr, *d_first = nullptr, *d_last = nullptr;
+    auto cleanup = [&](int code) {
+        if (d_flag) (void)hipFree(d_flag);
+        if (d_mlo) (void)hipFree(d_mlo);
+        if (d_mhi) (void)hipFree(d_mhi);
+        if (d_first) (void)hipFree(d_first);
+        if (d_last) (void)hipFree(d_last);
+        if (code != CFD_OK) cfd_multi_destroy(m);
+        return code;
+    };
+    if (hipSetDevice(dev) != hipSuccess) return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: hipSetDevice failed"));
+    if (world > 1) {
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof id);
+        ncclResult_t r = ncclCommInitRank(&s.comm, world, id, rank);
+        if (r != ncclSuccess) return cleanup(fail(CFD_E_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)));
+    }
+    // agree on the 2-D form: minimum over the ranks of "my W is identically +0"
+    int mine = p->nz == 1 && !(p->flags & CFD_FLAG_FORCE_3D) && w_identically_zero(fields[2], (size_t)p->nx * m->plane);
+    int all = mine;
+    if ((rc = streams_for(m, dev, &s.ds)) != CFD_OK) return cleanup(rc);
+    st = main_of(m, s);
+    if (world > 1) {
+        if (hipMalloc((void**)&d_flag, sizeof(int)) != hipSuccess ||
+            hipMemcpyAsync(d_flag, &mine, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+            return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: device buffer for the agreement failed"));
+        ncclResult_t r = ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, s.comm, st);
+        if (r != ncclSuccess) return cleanup(fail(CFD_E_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r)));
+        if (hipMemcpyAsync(&all, d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: reading the agreement back failed"));
+    }
+    const int extra = all ? 0 : (p->nz == 1 ? CFD_FLAG_FORCE_3D : 0);
+    if ((rc = make_slab(m, s, fields, active, extra)) != CFD_OK) return cleanup(rc);
+    if (world > 1) {
+        // neighbours swap the masks of their first / last plane
+        const size_t pb = m->plane;
+        if (hipMalloc((void**)&d_first, pb) != hipSuccess || hipMalloc((void**)&d_last, pb) != hipSuccess ||
+            hipMalloc((void**)&d_mlo, pb) != hipSuccess || hipMalloc((void**)&d_mhi, pb) != hipSuccess ||
+            hipMemcpyAsync(d_first, active, pb, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_last, active + (size_t)(p->nx - 1) * pb, pb, hipMemcpyHostToDevice, st) != hipSuccess)
+            return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: device buffers for the mask planes failed"));
+        ncclResult_t r = ncclGroupStart();
+        if (r == ncclSuccess && rank > 0) r = ncclSend(d_first, pb, ncclUint8, rank - 1, s.comm, st);
+        if (r == ncclSuccess && rank > 0) r = ncclRecv(d_mlo, pb, ncclUint8, rank - 1, s.comm, st);
+        if (r == ncclSuccess && rank < world - 1) r = ncclSend(d_last, pb, ncclUint8, rank + 1, s.comm, st);
+        if (r == ncclSuccess && rank < world - 1) r = ncclRecv(d_mhi, pb, ncclUint8, rank + 1, s.comm, st);
+        if (r == ncclSuccess) r = ncclGroupEnd();
+        if (r != ncclSuccess) return cleanup(fail(CFD_E_DEVICE, std::string("mask exchange: ") + ncclGetErrorString(r)));
+        std::vector<uint8_t> lo(pb), hi(pb);
+        if ((rank > 0 && hipMemcpyAsync(lo.data(), d_mlo, pb, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            (rank < world - 1 && hipMemcpyAsync(hi.data(), d_mhi, pb, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: reading the mask planes back failed"));
+        if ((rc = cfd_set_ghost_active(s.h, rank > 0 ? lo.data() : nullptr, rank < world - 1 ? hi.data() : nullptr)) != CFD_OK)
+            return cleanup(rc);
+        int ok = 0;
+        if ((rc = cfd_pair_available(s.h, &ok)) != CFD_OK) return cleanup(rc);
+        ok = ok && env_flag("CFD_MULTI_PAIR", true);
+        if (hipMemcpyAsync(d_flag, &ok, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+            return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: agreement on the step form failed"));
+        r = ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, s.comm, st);
+        if (r != ncclSuccess) return cleanup(fail(CFD_E_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r)));
+        if (hipMemcpyAsync(&ok, d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: agreement on the step form failed"));
+        m->pair = ok != 0;
+    }
+    cleanup(CFD_OK);
+    *out = m;
+    return CFD_OK;
+}
+
+int cfd_multi_step(cfd_multi* m, int nsteps) {
+    if (!m) return fail(CFD_E_ARG, "cfd_multi_step: null handle");
+    if (nsteps < 0) return fail(CFD_E_ARG, "cfd_multi_step: nsteps must be >= 0");
+    for (int i = 0; i < nsteps; ++i) M_CFD(step_once(m));
+    return CFD_OK;
+}
+
+int cfd_multi_sync(cfd_multi* m) {
+    if (!m) return fail(CFD_E_ARG, "cfd_multi_sync: null handle");
+    for (DeviceStreams& d : m->streams) {
+        M_HIP(hipSetDevice(d.device));
+        M_HIP(hipStreamSynchronize(d.side));
+        M_HIP(hipStreamSynchronize(d.main));
+    }
+    return CFD_OK;
+}
+
+int cfd_multi_total_density(cfd_multi* m, double* out) {
+    if (!m || !out) return fail(CFD_E_ARG, "cfd_multi_total_density: null pointer");
+    if (m->transport == CFD_TRANSPORT_RCCL && m->world > 1) {
+        // per-slab tree sums on the device, one all-reduce of a double, one copy to the host
+        for (Slab& s : m->slab) M_CFD(cfd_total_density_noalloc(s.h, s.d_sum));
+        M_NCCL(ncclGroupStart());
+        for (Slab& s : m->slab) M_NCCL(ncclAllReduce(s.d_sum, s.d_sum, 1, ncclDouble, ncclSum, s.comm, main_of(m, s)));
+        M_NCCL(ncclGroupEnd());
+        Slab& s0 = m->slab[0];
+        M_HIP(hipSetDevice(s0.device));
+        M_HIP(hipMemcpyAsync(out, s0.d_sum, sizeof(double), hipMemcpyDeviceToHost, main_of(m, s0)));
+        return cfd_multi_sync(m);
+    }
+    double acc = 0.0;
+    for (Slab& s : m->slab) {       // slabs in x order: a deterministic sum
+        double v = 0.0;
+        M_CFD(cfd_total_density(s.h, &v));
+        acc += v;
+    }
+    *out = acc;
+    return CFD_OK;
+}
+
+int cfd_multi_read_fields(cfd_multi* m, int slot_rel, double* const out[CFD_NPROP]) {
+    if (!m || !out) return fail(CFD_E_ARG, "cfd_multi_read_fields: null pointer");
+    M_CFD(cfd_multi_sync(m));
+    for (Slab& s : m->slab) {
+        double* o[CFD_NPROP];
+        for (int k = 0; k < CFD_NPROP; ++k) {
+            if (!out[k]) return fail(CFD_E_ARG, "cfd_multi_read_fields: null output pointer");
+            o[k] = out[k] + (size_t)s.x0 * m->plane;
+        }
+        M_CFD(cfd_read_fields(s.h, slot_rel, o));
+    }
+    return CFD_OK;
+}
+
+int cfd_multi_time(cfd_multi* m, int* curr_mod_time, int* curr_abs_time) {
+    if (!m || !curr_mod_time || !curr_abs_time) return fail(CFD_E_ARG, "cfd_multi_time: null pointer");
+    *curr_mod_time = m->cmt;
+    *curr_abs_time = m->cat;
+    return CFD_OK;
+}
+
+int cfd_multi_info(cfd_multi* m, int* local_slabs, int* one_pass_tail, int* overlapped) {
+    if (!m) return fail(CFD_E_ARG, "cfd_multi_info: null handle");
+    if (local_slabs) *local_slabs = (int)m->slab.size();
+    if (one_pass_tail) *one_pass_tail = m->pair ? 1 : 0;
+    if (overlapped) *overlapped = (m->pair && m->overlap && m->world > 1) ? 1 : 0;
+    return CFD_OK;
+}
+
+int cfd_multi_slab(cfd_multi* m, int i, cfd_handle** h, int* x0, int* x1) {
+    if (!m) return fail(CFD_E_ARG, "cfd_multi_slab: null handle");
+    if (i < 0 || i >= (int)m->slab.size()) return fail(CFD_E_ARG, "cfd_multi_slab: no such local slab");
+    if (h) *h = m->slab[i].h;
+    if (x0) *x0 = m->slab[i].x0;
+    if (x1) *x1 = m->slab[i].x1;
+    return CFD_OK;
+}
+
+// Sends `bytes` of device memory to this rank itself through RCCL (one-rank communicator, grouped send +
+// receive) and all-reduces a double: proves on a one-GPU machine that the library's RCCL binding loads, builds
+// a communicator and moves data with the call pattern the exchange uses.
+int cfd_rccl_selftest(int device, size_t bytes) {
+    if (bytes < 8 || bytes % 8) return fail(CFD_E_ARG, "cfd_rccl_selftest: bytes must be a positive multiple of 8");
+    M_HIP(hipSetDevice(device));
+    const size_t n = bytes / 8;
+    std::vector<double> hsrc(n), hdst(n, 0.0);
+    for (size_t i = 0; i < n; ++i) hsrc[i] = 1.0 + (double)(i % 1021) * 0.25;
+    double *a = nullptr, *b = nullptr, *c = nullptr;
+    hipStream_t st = nullptr;
+    ncclComm_t comm = nullptr;
+    int rc = CFD_OK;
+    auto done = [&](int code) {
+        if (comm) (void)ncclCommDestroy(comm);
+        if (st) (void)hipStreamDestroy(st);
+        if (a) (void)hipFree(a);
+        if (b) (void)hipFree(b);
+        if (c) (void)hipFree(c);
+        return code;
+    };
+    if (hipMalloc((void**)&a, bytes) != hipSuccess || hipMalloc((void**)&b, bytes) != hipSuccess ||
+        hipMalloc((void**)&c, 8) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+        return done(fail(CFD_E_MEMORY, "cfd_rccl_selftest: allocation failed"));
+    const int devs[1] = {device};
+    ncclResult_t r = ncclCommInitAll(&comm, 1, devs);
+    if (r != ncclSuccess) return done(fail(CFD_E_DEVICE, std::string("ncclCommInitAll: ") + ncclGetErrorString(r)));
+    const double two = 2.0;
+    if (hipMemcpyAsync(a, hsrc.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(b, 0, bytes, st) != hipSuccess || hipMemcpyAsync(c, &two, 8, hipMemcpyHostToDevice, st) != hipSuccess)
+        return done(fail(CFD_E_DEVICE, "cfd_rccl_selftest: upload failed"));
+    r = ncclGroupStart();
+    if (r == ncclSuccess) r = ncclSend(a, n, ncclDouble, 0, comm, st);
+    if (r == ncclSuccess) r = ncclRecv(b, n, ncclDouble, 0, comm, st);
+    if (r == ncclSuccess) r = ncclGroupEnd();
+    if (r == ncclSuccess) r = ncclAllReduce(c, c, 1, ncclDouble, ncclSum, comm, st);
+    if (r != ncclSuccess) return done(fail(CFD_E_DEVICE, std::string("RCCL send/recv/all-reduce: ") + ncclGetErrorString(r)));
+    double sum = 0.0;
+    if (hipMemcpyAsync(hdst.data(), b, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&sum, c, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return done(fail(CFD_E_DEVICE, "cfd_rccl_selftest: download failed"));
+    if (std::memcmp(hsrc.data(), hdst.data(), bytes) != 0 || sum != 2.0)
+        rc = fail(CFD_E_STATE, "cfd_rccl_selftest: data came back changed");
+    return done(rc);
+}
+
+}  // extern "C"

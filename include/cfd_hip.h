@@ -276,6 +276,74 @@ int cfd_kernel_timing(cfd_handle *h, int kind, double *total_ms, int64_t *launch
  * zero (W then stays exactly zero, so it is neither read nor written), else 6. */
 int cfd_live_fields(cfd_handle *h, int *nfields);
 
+/* ---- several slabs behind one handle (no counterpart in the single-process, single-device reference) ----
+ *
+ * The x-slab decomposition driven by the library itself: the host keeps the reference's one-thread solve
+ * loop (src/Main.hs:278-306) and calls cfd_multi_step / cfd_multi_total_density in place of runSingleStep /
+ * totalDensity; the library cuts the grid into slabs of consecutive x-planes (x is the slowest index of the
+ * node order, src/SolutionDomain.hs:388-392, so a slab is a contiguous range of every field), exchanges the
+ * ghost planes before every sweep and overlaps the exchanges with the interior planes.  Results are
+ * identical to the undecomposed run, bit for bit, except the density sum (its order of summation).
+ */
+typedef struct cfd_multi cfd_multi;
+
+enum {
+    CFD_TRANSPORT_COPY = 0,     /* device-to-device / peer copies; any number of slabs per device, one process */
+    CFD_TRANSPORT_RCCL = 1      /* grouped ncclSend / ncclRecv between neighbours, ncclAllReduce for the density sum */
+};
+
+/* One host thread, every slab in this process.  p describes the WHOLE grid (p->device and ghost_* are
+ * ignored); fields / active as for cfd_create.  devices[i] = HIP device of slab i (NULL: slab i on device
+ * i modulo the device count).  CFD_TRANSPORT_RCCL: one slab per device (ncclCommInitAll over them).
+ * CFD_TRANSPORT_COPY: slabs may share a device (on one GPU this runs the whole decomposition, halo planes
+ * copied in place of sent).  Whether W is kept (cfd_live_fields) is decided on the whole grid, so that every
+ * slab's planes have the same size. */
+int cfd_multi_create(const cfd_params *p, int n_slabs, const int32_t *devices, int transport,
+                     const double *const fields[CFD_NPROP], const uint8_t *active, cfd_multi **out);
+
+/* One process per GPU: this process holds slab `rank` of `world` (p, fields, active describe that slab only:
+ * p->nx = its planes, p->device = its GPU, -1 = the current one).  The slabs talk through RCCL with a
+ * communicator built from id128, the 128 bytes cfd_comm_unique_id wrote on ONE rank and the host sent to all
+ * (any host-side channel: MPI, a file, torch.distributed).  Collective: every rank calls it, and afterwards
+ * cfd_multi_step / cfd_multi_total_density, the same number of times. */
+#define CFD_COMM_ID_BYTES 128
+int cfd_comm_unique_id(void *id128);
+int cfd_multi_create_rank(const cfd_params *p, int rank, int world, const void *id128,
+                          const double *const fields[CFD_NPROP], const uint8_t *active, cfd_multi **out);
+
+void cfd_multi_destroy(cfd_multi *m);
+
+/* runSingleStep (src/Main.hs:192-200) nsteps times on every slab: per step three sweeps with a one-plane
+ * exchange before each, or -- where every slab can run cfd_sweep_pair_and_filter -- one sweep, a two-plane
+ * exchange and the one-pass tail, both exchanges queued on a side stream beside the first sweep's interior
+ * planes.  Asynchronous: returns when the work is queued. */
+int cfd_multi_step(cfd_multi *m, int nsteps);
+
+/* totalDensity (src/Main.hs:269-270) over all slabs.  RCCL: per-slab sums on the device and one ncclAllReduce
+ * of a double (every rank gets the sum); copies: the per-slab sums added on the host in x order. */
+int cfd_multi_total_density(cfd_multi *m, double *out);
+
+/* cfd_read_fields of every local slab into the caller's arrays: out[i] holds the planes of all local slabs
+ * (the whole grid after cfd_multi_create, the rank's slab after cfd_multi_create_rank). */
+int cfd_multi_read_fields(cfd_multi *m, int slot_rel, double *const out[CFD_NPROP]);
+
+int cfd_multi_time(cfd_multi *m, int *curr_mod_time, int *curr_abs_time);
+
+/* Blocks until everything queued by the handle has finished on every device. */
+int cfd_multi_sync(cfd_multi *m);
+
+/* How the handle runs: slabs held by this process, whether a step's tail is the one-pass form, whether its
+ * exchanges run on the side stream beside the interior planes. */
+int cfd_multi_info(cfd_multi *m, int *local_slabs, int *one_pass_tail, int *overlapped);
+
+/* Local slab i: its single-slab handle (for cfd_set_timing / cfd_kernel_timing / cfd_property_slice; do not
+ * step or destroy it) and its plane range [x0, x1) within the arrays given at creation. */
+int cfd_multi_slab(cfd_multi *m, int i, cfd_handle **h, int *x0, int *x1);
+
+/* RCCL on one GPU: a one-rank communicator sends `bytes` of device memory to itself (grouped send + receive,
+ * the exchange's call pattern) and all-reduces a double; CFD_OK if the data came back unchanged. */
+int cfd_rccl_selftest(int device, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

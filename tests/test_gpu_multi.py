@@ -1,0 +1,107 @@
+"""The slab decomposition behind the C ABI (cfd_multi_*): several slabs driven by the library itself, halo
+planes moved by device copies (any number of slabs on the one GPU of the test box) -- bit-identical to the
+undecomposed run in all three slots; the density sum to 1e-12; RCCL itself through a one-rank communicator."""
+import numpy as np
+import pytest
+
+from helpers import PROPS, bits_equal, small_case
+
+pytestmark = pytest.mark.gpu
+FAST = 4
+
+
+def _single(params, fields, active, flags):
+    from cfd_amd.solver import AdjGraph
+    return AdjGraph(dict(params, flags=flags), fields, active)
+
+
+def _multi(params, fields, active, flags, n, **kw):
+    from cfd_amd.multi import MultiGraph
+    return MultiGraph(dict(params, flags=flags), fields, active, n, devices=[0] * n, **kw)
+
+
+def _assert_same(m, g, what):
+    assert (m.currModTime, m.currAbsTime) == (g.currModTime, g.currAbsTime)
+    for rel in range(3):
+        fm, fg = m.read_fields(rel), g.read_fields(rel)
+        for k in range(7):
+            assert bits_equal(fm[k], fg[k]), (what, rel, PROPS[k], float(np.max(np.abs(fm[k] - fg[k]))))
+    a, b = m.total_density(), g.total_density()
+    assert abs(a - b) <= 1e-12 * abs(b)
+
+
+@pytest.mark.parametrize("n,shape,flags", [(2, (12, 33, 1), FAST), (3, (15, 300, 1), FAST), (5, (71, 500, 1), FAST),
+                                           (4, (9, 20, 1), FAST), (3, (7, 50, 1), FAST), (2, (40, 33, 1), 0),
+                                           (3, (11, 6, 5), FAST), (4, (21, 18, 19), FAST), (2, (9, 8, 7), 0)])
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_virtual_slabs_behind_the_c_abi_match_the_undecomposed_run(n, shape, flags, overlap, monkeypatch):
+    monkeypatch.setenv("CFD_MULTI_OVERLAP", overlap)
+    params, fields, active = small_case(shape[0], shape[1], shape[2], 61)
+    # inactive cells on the planes next to a slab boundary: the once-swept ghost values depend on their masks
+    act = np.array(active).reshape(shape)
+    act[shape[0] // n, ::3, :] = 0
+    act[max(shape[0] // n - 1, 0), 1::4, :] = 0
+    active = act.reshape(-1)
+    g = _single(params, fields, active, flags)
+    m = _multi(params, fields, active, flags, n)
+    local, one_pass, overlapped = m.info()
+    assert local == n
+    if flags == FAST and shape[2] == 1 and min((shape[0] * (i + 1)) // n - (shape[0] * i) // n for i in range(n)) >= 2:
+        assert one_pass and overlapped == (overlap == "1")
+    for step in range(3):
+        g.step(1)
+        m.step(1)
+        _assert_same(m, g, "step %d" % step)
+    g.step(2)
+    m.step(2)
+    _assert_same(m, g, "two more steps")
+
+
+def test_one_slab_is_the_plain_library():
+    params, fields, active = small_case(30, 40, 1, 62)
+    g = _single(params, fields, active, FAST)
+    m = _multi(params, fields, active, FAST, 1)
+    g.step(3); m.step(3)
+    _assert_same(m, g, "one slab")
+
+
+def test_w_in_one_slab_only_keeps_w_everywhere():
+    """nz == 1 with W != 0 in the last slab only: whether the device holds W is decided on the whole grid, so the
+    first slab (whose own W is identically zero) keeps W too and the planes the slabs exchange have one size."""
+    params, fields, active = small_case(16, 12, 1, 63)
+    fields = [np.array(f, dtype=np.float64) for f in fields]
+    fields[2][-12 * 3:] = 0.05 * np.cos(np.arange(36))
+    g = _single(params, fields, active, FAST)
+    assert g.live_fields == 6
+    m = _multi(params, fields, active, FAST, 2)
+    assert m.slab(0).live_fields == 6 and m.slab(1).live_fields == 6
+    g.step(3); m.step(3)
+    _assert_same(m, g, "W in one slab")
+    assert np.any(m.read_fields(0)[2][:12 * 8] != 0.0)         # W has been advected into the first slab
+
+
+def test_rccl_through_the_library_on_one_gpu():
+    """A one-rank RCCL communicator built by the library: grouped send + receive to itself and an all-reduce; and
+    the RCCL transport with a single slab (no neighbour) steps like the plain library."""
+    from cfd_amd.multi import MultiGraph, comm_unique_id, rccl_selftest
+    rccl_selftest(0, 1 << 20)
+    assert len(comm_unique_id()) == 128
+    params, fields, active = small_case(20, 30, 1, 64)
+    g = _single(params, fields, active, FAST)
+    m = MultiGraph(dict(params, flags=FAST), fields, active, 1, devices=[0], transport="rccl")
+    r = MultiGraph.for_rank(dict(params, flags=FAST, device=0), fields, active, 0, 1, None)
+    g.step(2); m.step(2); r.step(2)
+    _assert_same(m, g, "rccl, one slab")
+    _assert_same(r, g, "rank form, world 1")
+
+
+def test_multi_error_paths():
+    from cfd_amd._capi import CfdError
+    from cfd_amd.multi import MultiGraph
+    params, fields, active = small_case(6, 5, 1, 65)
+    with pytest.raises(CfdError):
+        MultiGraph(params, fields, active, 7, devices=[0] * 7)             # more slabs than planes
+    with pytest.raises(CfdError):
+        MultiGraph(params, fields, active, 2, devices=[0, 0], transport="rccl")    # RCCL: one slab per device
+    with pytest.raises(CfdError):
+        MultiGraph(params, fields, active, 2, devices=[0, 99])
