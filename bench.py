@@ -65,6 +65,13 @@ def parse():
     ap.add_argument("--flags", type=int, default=0, help="extra cfd_params.flags (1 = one-thread-per-cell kernel)")
     ap.add_argument("--warmup-seconds", type=float, default=0.5,
                     help="keep warming up until this much time has been spent in steps")
+    ap.add_argument("--slab-driver", choices=("c", "torch"), default="c",
+                    help="who drives the slabs at N > 1: the library itself (cfd_multi_*: RCCL called from C, the "
+                         "process group is gloo and carries only the communicator id, barriers and the timing "
+                         "reduction) or cfd_amd.slab on torch.distributed's nccl backend")
+    ap.add_argument("--virtual-slabs", type=int, default=1,
+                    help="N = 1 only: cut this GPU's grid into K slabs driven by the library (copy transport), to "
+                         "measure what the decomposition itself costs")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse launch + rendezvous + reduction without a GPU (gloo, no compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -214,8 +221,12 @@ def main():
     torch.cuda.set_device(local_rank)
     from cfd_amd import cases
     from cfd_amd.slab import SlabGraph, init_rccl
-    if world > 1:
+    c_driver = a.slab_driver == "c" and (world > 1 or a.virtual_slabs > 1)
+    if world > 1 and c_driver:
+        dist.init_process_group("gloo")                 # control plane only; the halo planes go through the library's RCCL
+    elif world > 1:
         init_rccl(torch.device("cuda", local_rank))     # rank, world size and rendezvous from the environment
+    red_dev = "cpu" if (world > 1 and c_driver) else "cuda"
 
     global_nx = a.nx if a.strong else a.nx * world
     if a.strong:
@@ -235,7 +246,36 @@ def main():
     params["device"] = local_rank
     params["dt"] = a.dt
     params["flags"] = a.flags | (4 if a.arith == "fast" else 0)
-    g = SlabGraph(params, fields, active, rank=rank, world=world)
+    if c_driver:
+        from cfd_amd.multi import MultiGraph, comm_unique_id
+
+        class LibrarySlabs:
+            """The slabs of this process behind cfd_multi_*, with the few verbs the loop below uses."""
+
+            def __init__(self):
+                if world > 1:
+                    box = [comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    self.m = MultiGraph.for_rank(params, fields, active, rank, world, box[0])
+                else:
+                    self.m = MultiGraph(params, fields, active, a.virtual_slabs, devices=[local_rank] * a.virtual_slabs)
+                self.graph = self.m.slab(0)
+
+            def step(self, n=1):
+                self.m.step(n)
+
+            def sync(self):
+                self.m.sync()
+
+            def total_density(self):
+                return self.m.total_density()
+
+            def close(self):
+                self.m.close()
+
+        g = LibrarySlabs()
+    else:
+        g = SlabGraph(params, fields, active, rank=rank, world=world)
 
     def barrier():
         if world > 1:
@@ -250,7 +290,7 @@ def main():
     # warm up by time as well: every rank derives the same number of extra steps from the slowest rank's time
     tw = time.perf_counter() - tw
     if world > 1:
-        t = torch.tensor([tw], dtype=torch.float64, device="cuda")
+        t = torch.tensor([tw], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tw = float(t.item())
     warmup_extra = 0
@@ -277,16 +317,20 @@ def main():
     g.graph.set_timing(False)
     base_name = g.graph.kernel_name()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if c_driver and a.virtual_slabs > 1:
+        # launches were timed on the first of the K slabs only: scale to the whole GPU
+        scale = a.virtual_slabs
+        kernel_ms, fused_ms, pair_ms = kernel_ms * scale, fused_ms * scale, pair_ms * scale
     cells_per_gpu = a.nx * a.ny * a.nz                   # this rank's cells (rank 0 reports)
     total_cells = global_nx * a.ny * a.nz
     final_density = g.total_density()
 
     strict = None
-    if a.arith == "fast" and world == 1:
+    if a.arith == "fast" and world == 1 and not c_driver:
         # the strict-order kernel on the same workload, a few steps, for the record
         g.close()
         params["flags"] = a.flags
@@ -360,7 +404,11 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "cells_per_gpu": cells_per_gpu, "sweeps_per_step": SWEEPS_PER_STEP,
-                   "filter_passes_per_step": 1, "decomposition": "x-slabs, %d rank(s)" % world,
+                   "filter_passes_per_step": 1,
+                   "decomposition": "x-slabs, %d rank(s)%s%s" % (
+                       world, ", %d slabs on this GPU" % a.virtual_slabs if a.virtual_slabs > 1 else "",
+                       (", driven by the library (cfd_multi_*: %s)" % ("RCCL" if world > 1 else "device copies"))
+                       if c_driver else (", driven by cfd_amd.slab over torch.distributed" if world > 1 else "")),
                    "kernel": kernel_name, "arithmetic": a.arith, "dt": a.dt,
                    "fields_finite_at_end": bool(final_density == final_density and abs(final_density) != float("inf"))},
         # the launch kind that takes most of the timed region; every kind is listed under "kernels"

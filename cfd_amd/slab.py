@@ -203,14 +203,27 @@ class DistComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def agree_two_d(self, mine):
+        """Whether EVERY rank's W is identically +0 (a collective, before any backend exists): the device form
+        without W is a property of the whole grid -- slabs that disagreed would exchange planes of different
+        sizes."""
+        if self.world == 1:
+            return mine
+        import torch
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([1.0 if mine else 0.0], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
 
 class LocalComm:
     """Virtual ranks: all slabs live in this process; `peers` is the list of SlabGraphs in rank
     order.  Exchange copies planes directly; used to test ghost-plane handling on one device."""
 
-    def __init__(self, rank, peers):
+    def __init__(self, rank, peers, all_w_zero=None):
         self.rank, self.peers = rank, peers
         self.world = None
+        self.all_w_zero = all_w_zero
 
     def exchange(self, backend, depth=1):
         # pull model: every rank copies what it needs from its neighbours' send planes
@@ -240,26 +253,47 @@ class LocalComm:
         return all(g.backend.pair_available() for g in self.peers)
 
     def all_sum(self, backend, v):
-        raise NotImplementedError("sum over virtual ranks is done by the caller")
+        """Sum over the virtual ranks, in rank order (every slab computes its own part: called on any of them,
+        it returns the whole)."""
+        acc = 0.0
+        for g in self.peers:
+            acc += g.backend.total_density()
+        return acc
+
+    def agree_two_d(self, mine):
+        """Virtual ranks are built one after the other, so the decision is the caller's: pass all_w_zero to
+        every LocalComm (default: each slab judges by its own W, as a single slab does)."""
+        return mine if self.all_w_zero is None else bool(self.all_w_zero)
 
 
 class SlabGraph:
     """One rank's slab.  `fields` / `active` hold this rank's owned planes only."""
 
     def __init__(self, params, fields, active, rank=0, world=1, comm=None, backend_cls=GpuBackend, pair=True,
-                 overlap=True):
+                 overlap=None):
         """pair=False keeps the three-sweeps-per-step form (one-plane halos only) even where the one-pass
         tail is available; every rank must pass the same value.  overlap=False keeps the two-plane exchange
-        of the one-pass tail on the main stream, behind the whole first sweep."""
+        of the one-pass tail on the main stream, behind the whole first sweep.  overlap=None: False for real
+        ranks over torch.distributed (that form -- side stream, process-group stream and RCCL's own streams
+        waiting on each other -- has only ever run with one rank; CFD_SLAB_OVERLAP=1 turns it on), True
+        otherwise.  The library's own driver (cfd_multi_*, cfd_amd.multi) is the default at N > 1."""
         p = dict(params)
         p["ghost_lo"] = 1 if rank > 0 else 0
         p["ghost_hi"] = 1 if rank < world - 1 else 0
         self.rank, self.world = rank, world
+        self.comm = comm if comm is not None else DistComm(rank, world)
+        # nz == 1: the library drops W where it is identically +0 -- decided on the whole grid, not per slab
+        if p["nz"] == 1 and world > 1 and hasattr(self.comm, "agree_two_d"):
+            mine = not np.ascontiguousarray(fields[2], dtype=np.float64).view(np.uint64).any()
+            everyone = self.comm.agree_two_d(mine)      # a collective: every rank calls it, whatever its own W
+            if mine and not everyone:
+                p["flags"] = int(p.get("flags", 0)) | 2         # CFD_FLAG_FORCE_3D: another slab has W != 0
         self.backend = backend_cls(p, fields, active)
         self.graph = self.backend.graph if hasattr(self.backend, "graph") else self.backend
-        self.comm = comm if comm is not None else DistComm(rank, world)
         self._masks_set = False
         self._use_pair = None if pair else False
+        if overlap is None:
+            overlap = not (isinstance(self.comm, DistComm) and world > 1) or os.environ.get("CFD_SLAB_OVERLAP") == "1"
         self.overlap = overlap
 
     def set_ghost_masks(self):

@@ -3,7 +3,12 @@
 // host binds it.  Plain C++ (no HIP on the host side); links only against include/cfd_hip.h's
 // entry points.
 //
-//   cfd_main [steps] [--fast] [--nx N --ny N] [--string-domain PROPERTY]
+//   cfd_main [steps] [--fast] [--nx N --ny N] [--string-domain PROPERTY] [--gpus N | --slabs N]
+//
+// --gpus N: the grid cut into N x-slabs, one per GPU, halo planes through RCCL (cfd_multi_create with
+// CFD_TRANSPORT_RCCL); --slabs N: N slabs on the current GPU, halo planes copied (the same decomposition on a
+// one-GPU machine).  The loop and its five lines stay those of the reference; only the density sum's order
+// of summation differs from the undecomposed run.
 //
 // --string-domain k also prints, after every step, the slice of Property k (0 Speed .. 9 Dye) the way the
 // reference's stringDomain does (src/Main.hs:349-352; the call is commented out at :302).
@@ -56,11 +61,14 @@ int main(int argc, char** argv) {
     int nx = 301, ny = 151;
     uint32_t flags = 0;
     int show_prop = -1;
+    int n_slabs = 0, transport = CFD_TRANSPORT_COPY;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--fast")) flags |= CFD_FLAG_FAST_MATH;
         else if (!std::strcmp(argv[i], "--nx") && i + 1 < argc) nx = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--ny") && i + 1 < argc) ny = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--string-domain") && i + 1 < argc) show_prop = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) { n_slabs = std::atoi(argv[++i]); transport = CFD_TRANSPORT_RCCL; }
+        else if (!std::strcmp(argv[i], "--slabs") && i + 1 < argc) { n_slabs = std::atoi(argv[++i]); transport = CFD_TRANSPORT_COPY; }
         else steps = std::atol(argv[i]);
     }
     cfd_params p;
@@ -88,6 +96,25 @@ int main(int argc, char** argv) {
         }
     dye[(size_t)0 * ny + (ny - 1) / 2] = 1.0;
     const double* fields[CFD_NPROP] = {U.data(), V.data(), W.data(), rho.data(), T.data(), mew.data(), dye.data()};
+    if (n_slabs > 1) {
+        // the same loop over the slab decomposition: runSingleStep -> cfd_multi_step, totalDensity -> cfd_multi_total_density
+        cfd_multi* m = nullptr;
+        std::vector<int32_t> devs(n_slabs);
+        for (int i = 0; i < n_slabs; ++i) devs[i] = transport == CFD_TRANSPORT_RCCL ? i : 0;
+        if (cfd_multi_create(&p, n_slabs, devs.data(), transport, fields, active.data(), &m) != CFD_OK) return die("cfd_multi_create");
+        std::printf("starting ..... \n");
+        for (long step = 0; step < steps; ++step) {
+            if (cfd_multi_step(m, 1) != CFD_OK) return die("cfd_multi_step");
+            int cmt = 0, cat = 0;
+            double total = 0.0;
+            if (cfd_multi_time(m, &cmt, &cat) != CFD_OK) return die("cfd_multi_time");
+            if (cfd_multi_total_density(m, &total) != CFD_OK) return die("cfd_multi_total_density");
+            std::printf("%zu\nstep: %ld\ntimeLevel: %d\ntimeLevelAbsolute: %d\ntotalDensity: %s\n \n", n, step, cmt, cat,
+                        hs_show_double(total).c_str());
+        }
+        cfd_multi_destroy(m);
+        return 0;
+    }
     cfd_handle* h = nullptr;
     if (cfd_create(&p, fields, active.data(), &h) != CFD_OK) return die("cfd_create");
     std::printf("starting ..... \n");

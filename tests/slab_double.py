@@ -24,6 +24,7 @@ OUTPUT = ("Speed", "Vorticity", "Pressure", "U", "V", "W", "Density", "Temperatu
 class OracleSlabBackend:
     def __init__(self, params, fields, active):
         self.gl, self.gh = params["ghost_lo"], params["ghost_hi"]
+        self.flags = int(params.get("flags", 0))        # what the slab driver asked of the library
         self.nx = params["nx"]
         self.plane = params["ny"] * params["nz"]
         ext = dict(oracle_params(params))

@@ -105,3 +105,24 @@ def test_multi_error_paths():
         MultiGraph(params, fields, active, 2, devices=[0, 0], transport="rccl")    # RCCL: one slab per device
     with pytest.raises(CfdError):
         MultiGraph(params, fields, active, 2, devices=[0, 99])
+
+
+def test_compiled_host_over_three_slabs_prints_the_reference_stdout():
+    """driver/cfd_main --slabs 3: the reference's loop over cfd_multi_* (C++, no Python in the loop), the shipped
+    case cut into three slabs on this GPU: the same five lines per step as the golden transcript."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "driver", "cfd_main")
+    assert os.path.exists(exe), "build it with make -C driver (done by __graft_entry__.build())"
+    out = subprocess.run([exe, "5", "--slabs", "3"], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stderr
+    got = out.stdout.splitlines()
+    want = open(os.path.join(root, "tests", "golden", "shipped_case_stdout_5steps.txt")).read().splitlines()
+    assert got[0] == "starting ..... " and len(got) - 1 == len(want)
+    for a, b in zip(got[1:], want):
+        if a.startswith("totalDensity: "):
+            x, y = float(a.split()[1]), float(b.split()[1])
+            assert abs(x - y) <= 1e-12 * abs(y), (a, b)
+        else:
+            assert a == b

@@ -87,3 +87,57 @@ def test_slabs_match_single_domain(world, shape, pair, used, overlap):
             for k in range(7):
                 assert bits_equal(slots[rel][k], want[k][x0 * plane:x1 * plane]), (rank, rel, k)
         assert abs(td - ref.total_density()) <= 1e-12 * abs(ref.total_density())
+
+
+def _rank_w(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from helpers import small_case
+    from cfd_amd.slab import DistComm, SlabGraph, split_slabs
+    from slab_double import OracleSlabBackend
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        nx, ny = 12, 9
+        params, fields, active = small_case(nx, ny, 1, seed=33)
+        fields = [np.array(f, dtype=np.float64) for f in fields]
+        fields[2][-ny * 2:] = 0.03          # W != 0 in the last two planes only: the last rank's slab
+        x0, x1, f, a = split_slabs(fields, active, nx, ny, world)[rank]
+        p = dict(params)
+        p["nx"] = x1 - x0
+        g = SlabGraph(p, f, a, rank=rank, world=world, comm=DistComm(rank, world), backend_cls=OracleSlabBackend)
+        g.step(2)
+        q.put((rank, x0, x1, g.backend.flags, g.read_fields(0)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_w_in_one_slab_only_forces_the_general_form_on_every_rank():
+    """nz == 1 and W identically zero on rank 0 but not on rank 1: the ranks agree (all-reduce) before they create
+    their handles, and the rank with the zero W asks for CFD_FLAG_FORCE_3D, so that both hold six fields and
+    exchange planes of one size; W is advected into rank 0's slab as in the undecomposed run."""
+    sys.path.insert(0, HERE)
+    from helpers import bits_equal, oracle_params, small_case
+    from oracle import OracleB
+    nx, ny = 12, 9
+    params, fields, active = small_case(nx, ny, 1, seed=33)
+    fields = [np.array(f, dtype=np.float64) for f in fields]
+    fields[2][-ny * 2:] = 0.03
+    ref = OracleB(oracle_params(params), fields, active, pow_mode=1)
+    ref.step(2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_w, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = ref.read_fields(0)
+    for rank, x0, x1, flags, got in results:
+        assert bool(flags & 2) == (rank == 0), (rank, flags)        # rank 1 keeps W by itself
+        for k in range(7):
+            assert bits_equal(got[k], want[k][x0 * ny:x1 * ny]), (rank, k)
