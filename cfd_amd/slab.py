@@ -11,6 +11,8 @@ Per sweep:  start the exchange of the current slot's ghost planes, launch every 
 Per step:   3 such sweeps; the live filter pass needs no halo and is fused into the third sweep.
             Where the library can do the second and third sweep in one pass (2-D, re-associated
             arithmetic), the step is one such sweep, one exchange of TWO planes per side, and that pass.
+            (The library's own driver, cfd_multi_* / cfd_amd.multi, also hides both exchanges of such a
+            step behind the first sweep's interior planes; it is what bench.py uses at N > 1.)
 Reduction:  local tree sum of Density, then one all-reduce of a single double.
 
 Domain ends keep the reference's clamp-to-self rule (no wrap-around): rank 0 has no low
@@ -38,9 +40,6 @@ def init_rccl(device, high_priority=True, **kw):
     dist.init_process_group("nccl", device_id=device, pg_options=opts, **kw)
 
 
-_SIDE_STREAMS = {}      # device index -> the process's side stream on that device
-
-
 class _DeviceSpan:
     """Exposes a raw device address range to torch through the CUDA array interface."""
 
@@ -63,7 +62,6 @@ class GpuBackend:
         # run on torch's current stream so that torch.distributed's stream ordering covers the kernels
         self.graph.set_stream(torch.cuda.current_stream().cuda_stream)
         self._cache = {}
-        self._side = self._main = None
 
     def halo_tensors(self, depth=1):
         ptrs, nbytes = self.graph.halo_planes(depth)
@@ -92,33 +90,6 @@ class GpuBackend:
 
     def halo_commit(self, depth=1):
         """Received planes land directly in the time slot; nothing to unpack."""
-
-    # A second stream for the boundary work of a step (edge planes of the first sweep and both exchanges),
-    # so that it runs beside the interior launch on the main stream instead of behind it.
-    def fork(self):
-        """Orders the side stream after everything queued on the main stream so far."""
-        torch = self._torch
-        if self._side is None:
-            self._main = torch.cuda.current_stream()
-            # one side stream per device, shared by every slab of the process (normally there is one slab); high
-            # priority, so that its few blocks are dispatched ahead of the interior's
-            dev = torch.cuda.current_device()
-            if dev not in _SIDE_STREAMS:
-                _SIDE_STREAMS[dev] = torch.cuda.Stream(priority=int(os.environ.get("CFD_SIDE_PRIORITY", "-1")))
-            self._side = _SIDE_STREAMS[dev]
-        self._side.wait_stream(self._main)
-
-    def side(self):
-        """Context: torch work (and the process group's stream ordering) inside it refers to the side stream."""
-        return self._torch.cuda.stream(self._side)
-
-    def sweep_end_side(self):
-        """The edge planes of the open split sweep, launched on the side stream."""
-        self.graph.sweep_end(self._side.cuda_stream)
-
-    def join(self):
-        """Orders the main stream after the side stream."""
-        self._main.wait_stream(self._side)
 
     def scalar_tensor(self, v):
         return self._torch.tensor([v], dtype=self._torch.float64, device="cuda")
@@ -269,14 +240,11 @@ class LocalComm:
 class SlabGraph:
     """One rank's slab.  `fields` / `active` hold this rank's owned planes only."""
 
-    def __init__(self, params, fields, active, rank=0, world=1, comm=None, backend_cls=GpuBackend, pair=True,
-                 overlap=None):
+    def __init__(self, params, fields, active, rank=0, world=1, comm=None, backend_cls=GpuBackend, pair=True):
         """pair=False keeps the three-sweeps-per-step form (one-plane halos only) even where the one-pass
-        tail is available; every rank must pass the same value.  overlap=False keeps the two-plane exchange
-        of the one-pass tail on the main stream, behind the whole first sweep.  overlap=None: False for real
-        ranks over torch.distributed (that form -- side stream, process-group stream and RCCL's own streams
-        waiting on each other -- has only ever run with one rank; CFD_SLAB_OVERLAP=1 turns it on), True
-        otherwise.  The library's own driver (cfd_multi_*, cfd_amd.multi) is the default at N > 1."""
+        tail is available; every rank must pass the same value.  The form of a step that runs both exchanges
+        on a side stream beside the first sweep's interior planes lives in the library's own driver
+        (cfd_multi_*, cfd_amd.multi), on two non-blocking streams per device."""
         p = dict(params)
         p["ghost_lo"] = 1 if rank > 0 else 0
         p["ghost_hi"] = 1 if rank < world - 1 else 0
@@ -292,9 +260,6 @@ class SlabGraph:
         self.graph = self.backend.graph if hasattr(self.backend, "graph") else self.backend
         self._masks_set = False
         self._use_pair = None if pair else False
-        if overlap is None:
-            overlap = not (isinstance(self.comm, DistComm) and world > 1) or os.environ.get("CFD_SLAB_OVERLAP") == "1"
-        self.overlap = overlap
 
     def set_ghost_masks(self):
         """Hands the backend the neighbouring slabs' masks of the planes next to this slab (once; a
@@ -329,25 +294,6 @@ class SlabGraph:
         self.comm.exchange_wait(self.backend, reqs)
         self.backend.sweep_end()                            # first / last plane, slot rotation
 
-    def _step_overlapped(self):
-        """One step with both exchanges beside the first sweep's interior launch: the one-plane exchange,
-        the two planes next to each neighbour and the two-plane exchange of their results run on a side
-        stream while the main stream computes every other plane; the one-pass tail follows both."""
-        b, c = self.backend, self.comm
-        # Both the transport and the side stream are ordered after the previous step on the main stream.  The two
-        # markers this puts in front of the interior launch hold it back just long enough for the first exchange
-        # to be dispatched beside it: measured on MI355X, an exchange dispatched a few microseconds AFTER the
-        # interior launch finds no free compute unit until that launch ends.
-        reqs = c.exchange_start(b)
-        b.fork()
-        b.sweep_begin(True, False, edge=2)          # main stream: planes two or more away from a ghost plane
-        with b.side():
-            c.exchange_wait(b, reqs)                # side stream waits for the ghost planes
-            b.sweep_end_side()                      # two planes per side; the slot advances
-            c.exchange(b, depth=2)                  # their results, two planes per side, and the wait for them
-        b.join()
-        b.sweep_pair_and_filter()
-
     def sweep(self, step_time):
         self._sweep(step_time, False)
         return self
@@ -361,11 +307,7 @@ class SlabGraph:
             self.backend.step(nsteps)       # undecomposed: the library's own step (second and third sweep in one pass)
             return self
         pair = self.use_pair()
-        overlap = pair and self.overlap and hasattr(self.backend, "fork")
         for _ in range(nsteps):
-            if overlap:
-                self._step_overlapped()
-                continue
             self._sweep(True, False)
             if pair:
                 self.comm.exchange(self.backend, depth=2)       # two planes per side: both remaining sweeps

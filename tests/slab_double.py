@@ -111,20 +111,6 @@ class OracleSlabBackend:
     def sweep_begin(self, step_time, with_filter=False, edge=1):
         self._open = (step_time, with_filter)
 
-    # the side stream of the GPU backend: on the CPU everything is in program order already
-    def fork(self):
-        pass
-
-    def side(self):
-        import contextlib
-        return contextlib.nullcontext()
-
-    def sweep_end_side(self):
-        self.sweep_end()
-
-    def join(self):
-        pass
-
     def sweep_end(self):
         step_time, with_filter = self._open
         self.ob.sweep(step_time)

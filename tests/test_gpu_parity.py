@@ -320,10 +320,11 @@ def test_virtual_rank_slabs_two_sweeps_in_one_pass(world, shape, pair_chunk, mon
 
 
 @pytest.mark.parametrize("world,shape", [(2, (12, 33)), (3, (15, 300)), (4, (9, 20)), (2, (4, 7)), (3, (7, 50)), (5, (71, 500))])
-def test_virtual_rank_slabs_edge_planes_on_a_side_stream(world, shape):
-    """The first sweep of a step split two planes deep (cfd_sweep_begin_depth) with the edge planes launched on
-    another stream (cfd_sweep_end_on) beside the interior launch, then the one-pass tail: bit-exact against the
-    undecomposed run.  Slabs of 2, 3 and 4 planes have an empty or one-plane interior."""
+def test_virtual_rank_slabs_edge_planes_in_a_second_launch(world, shape):
+    """The first sweep of a step split two planes deep (cfd_sweep_begin_depth / cfd_sweep_end), then the one-pass
+    tail: bit-exact against the undecomposed run.  Slabs of 2, 3 and 4 planes have an empty or one-plane interior.
+    (The edge planes on a second stream beside the interior launch -- cfd_sweep_end_on -- are exercised by the
+    library's own slab driver, tests/test_gpu_multi.py.)"""
     import torch
     from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
     nx, ny = shape
@@ -341,24 +342,20 @@ def test_virtual_rank_slabs_edge_planes_on_a_side_stream(world, shape):
     for _ in range(3):
         for g in peers:
             g.exchange()
-        torch.cuda.synchronize()
         for g in peers:
-            g.backend.fork()
             g.backend.sweep_begin(True, False, edge=2)
         for g in peers:
-            g.backend.sweep_end_side()
-        torch.cuda.synchronize()
+            g.backend.sweep_end()
         for g in peers:
             g.comm.exchange(g.backend, depth=2)
-        torch.cuda.synchronize()
         for g in peers:
-            g.backend.join()
             g.backend.sweep_pair_and_filter()
     for r, g in enumerate(peers):
         for rel in range(3):
             got, want = g.read_fields(rel), ref.read_fields(rel)
             for k in range(7):
                 assert bits_equal(got[k], want[k][bounds[r] * ny:bounds[r + 1] * ny]), (r, rel, PROPS[k])
+    assert abs(peers[0].total_density() - ref.total_density()) <= 1e-12 * abs(ref.total_density())
 
 
 def test_split_sweep_with_filter_stays_on_the_own_stream():
@@ -730,9 +727,8 @@ def test_rccl_transport_on_aliased_halo_planes():
     # the two-plane halo of the one-pass tail and a mask plane (uint8) through the same transport
     assert "two-plane exchange ok: True" in out.stdout and "mask ok: True" in out.stdout, out.stdout
     assert "pair available: True" in out.stdout and "finite after the one-pass tail: True" in out.stdout, out.stdout
-    # SlabGraph.step's three N > 1 forms over the same transport (the rank as its own neighbour) agree bit for bit
-    assert "overlapped step ok: True forms: [True, True, False] finite: True" in out.stdout, out.stdout
-    assert "timing across two streams ok: True" in out.stdout, out.stdout
+    # SlabGraph.step's two N > 1 forms over the same transport (the rank as its own neighbour) agree bit for bit
+    assert "slab step forms agree: True forms: [True, False] finite: True" in out.stdout, out.stdout
 
 
 def test_compiled_host_prints_reference_stdout():

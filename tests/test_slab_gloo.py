@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _rank_main(rank, world, port, shape, pair, overlap, q):
+def _rank_main(rank, world, port, shape, pair, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import torch.distributed as dist
@@ -39,7 +39,7 @@ def _rank_main(rank, world, port, shape, pair, overlap, q):
         p = dict(params)
         p["nx"] = x1 - x0
         g = SlabGraph(p, f, a, rank=rank, world=world, comm=DistComm(rank, world), backend_cls=OracleSlabBackend,
-                      pair=pair, overlap=overlap)
+                      pair=pair)
         g.step(2)
         td = g.total_density()
         slices = [g.property_slice(k) for k in range(10)]      # collective: exchanges the ghost planes
@@ -52,14 +52,11 @@ def _rank_main(rank, world, port, shape, pair, overlap, q):
 # pair: the tail of a step as one pass behind a two-plane exchange (True) or as two sweeps with a one-plane
 # exchange each (False); used: what the ranks must have agreed on (a one-plane slab cannot send two planes,
 # and then no rank may use the two-plane form)
-# overlap: with the one-pass tail, both exchanges of a step issued beside the first sweep's interior planes
-# (SlabGraph._step_overlapped; the default) or the two-plane exchange after the whole first sweep
-@pytest.mark.parametrize("world,shape,pair,used,overlap", [
-    (2, (12, 9, 1), True, True, True), (3, (11, 6, 1), True, True, True), (2, (8, 5, 4), True, True, True),
-    (2, (12, 9, 1), True, True, False), (3, (11, 6, 1), True, True, False),
-    (2, (12, 9, 1), False, False, True), (3, (11, 6, 1), False, False, True),
-    (3, (4, 7, 1), True, False, True), (2, (4, 6, 1), True, True, True)])
-def test_slabs_match_single_domain(world, shape, pair, used, overlap):
+@pytest.mark.parametrize("world,shape,pair,used", [
+    (2, (12, 9, 1), True, True), (3, (11, 6, 1), True, True), (2, (8, 5, 4), True, True),
+    (2, (12, 9, 1), False, False), (3, (11, 6, 1), False, False),
+    (3, (4, 7, 1), True, False), (2, (4, 6, 1), True, True)])
+def test_slabs_match_single_domain(world, shape, pair, used):
     sys.path.insert(0, HERE)
     from helpers import bits_equal, oracle_params, small_case
     from oracle import OracleB
@@ -70,7 +67,7 @@ def test_slabs_match_single_domain(world, shape, pair, used, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, shape, pair, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, shape, pair, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
