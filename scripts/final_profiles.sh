@@ -1,7 +1,7 @@
 # usage: bash scripts/final_profiles.sh <tag>  -- the round's records: default bench, the same command under
 # rocprofv3 --kernel-trace --stats, counter passes for the 2-D and 3-D sweep kernels (separate runs)
 set -e
-TAG=${1:-final}
+TAG=${1:-final}   # e.g. r02_final: results under gpurun_out/$TAG, to be copied into profiles/<round>/
 O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
@@ -14,3 +14,6 @@ python3 scripts/pmc_summary.py $TAG/pmc2d > $O/pmc2d_summary.txt
 NZ=256 bash scripts/pmc.sh $TAG/pmc3d > $O/pmc3d.log 2>&1 || { tail -20 $O/pmc3d.log; exit 1; }
 python3 scripts/pmc_summary.py $TAG/pmc3d > $O/pmc3d_summary.txt
 grep -A22 "sweep" $O/pmc2d_summary.txt | head -60
+python3 scripts/record_traffic.py $O/pmc2d_summary.txt profiles/r02/final_pmc_4096sq.txt > $O/traffic.log
+timeout -k 10 600 python -u bench.py --nx 512 --ny 512 --nz 512 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_512cube.json 2> $O/bench_512cube.err || { tail -20 $O/bench_512cube.err; exit 1; }
+cut -c1-300 $O/bench_512cube.json
