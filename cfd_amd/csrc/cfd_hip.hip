@@ -115,6 +115,52 @@ static inline double* slot_base(const cfd_handle* h, int t) {
 // ------------------------------------------------------------------------------------------
 // Arithmetic policies for the 2-D kernels: the strict (reference operation order) and the fast
 // (re-associated) form of phase A / phase B share all of the kernel plumbing below.
+// A struct of doubles to / from a strided LDS column.
+template <class S>
+__device__ __forceinline__ void lds_put(double* __restrict__ l, int st, const S& s) {
+    constexpr int N = sizeof(S) / sizeof(double);
+    double v[N];
+    __builtin_memcpy(v, &s, sizeof(S));
+#pragma unroll
+    for (int i = 0; i < N; ++i) l[i * st] = v[i];
+}
+template <class S>
+__device__ __forceinline__ void lds_get(const double* __restrict__ l, int st, S& s) {
+    constexpr int N = sizeof(S) / sizeof(double);
+    double v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = l[i * st];
+    __builtin_memcpy(&s, v, sizeof(S));
+}
+
+// The doubles of a struct of doubles that `need` marks, to / from consecutive rows of a strided LDS column
+// (a share may carry products that no right-hand side reads through this channel).
+template <int N>
+__host__ __device__ constexpr int count_needed(bool (*need)(int)) {
+    int n = 0;
+    for (int i = 0; i < N; ++i) n += need(i) ? 1 : 0;
+    return n;
+}
+template <class S, class Need>
+__device__ __forceinline__ void lds_put_needed(double* __restrict__ l, int st, const S& s, Need need) {
+    constexpr int N = sizeof(S) / sizeof(double);
+    double v[N];
+    __builtin_memcpy(v, &s, sizeof(S));
+    int slot = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (need(i)) l[(slot++) * st] = v[i];
+}
+template <class S, class Need>
+__device__ __forceinline__ void lds_get_needed(const double* __restrict__ l, int st, S& s, Need need) {
+    constexpr int N = sizeof(S) / sizeof(double);
+    double v[N];
+    int slot = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = need(i) ? l[(slot++) * st] : 0.0;
+    __builtin_memcpy(&s, v, sizeof(S));
+}
+
 struct MathStrict2 {
     using Consts = SweepConsts;
     using PA = PhaseA2;
@@ -235,12 +281,19 @@ sweep2d_simple(typename M::Consts K, const double* __restrict__ src, double* __r
 }
 
 // Arithmetic policies for the 3-D kernels.
+// Products of ShareY3 / ShareZ3 that a right-hand side reads from a y / z neighbour (by position in the struct):
+// everything but the half-square of the velocity component along the share's own direction.
+__host__ __device__ constexpr bool need_sy3(int i) { return i != 8; }      // s.sqh[1]
+__host__ __device__ constexpr bool need_sz3(int i) { return i != 9; }      // s.sqh[2]
+
 struct MathStrict3 {
     using Consts = SweepConsts;
     using PA = PhaseA3;
     using SX = ShareX3;
     using SY = ShareY3;
     using SZ = ShareZ3;
+    static constexpr int NSY = count_needed<19>(need_sy3), NSZ = count_needed<25>(need_sz3);
+    static constexpr bool OWN_FROM_LDS = true;      // phase B re-reads the cell's own y / z products from LDS
     static constexpr const char* name = "strict";
     // stored U, V, W, Dye of the cell (which = 0..3)
     __device__ __forceinline__ static double own(const PA& a, int which) { return a.own[which]; }
@@ -251,6 +304,18 @@ struct MathStrict3 {
                                                   const SY& YP, const SY& YM, const SZ& ZP, const SZ& ZM, double* o) {
         phaseB3(K, C, XP, XM, YP, YM, ZP, ZM, o);
     }
+    __device__ __forceinline__ static void put_sy(double* __restrict__ l, int st, const SY& s) {
+        lds_put_needed(l, st, s, need_sy3);
+    }
+    __device__ __forceinline__ static void get_sy(const double* __restrict__ l, int st, SY& s) {
+        lds_get_needed(l, st, s, need_sy3);
+    }
+    __device__ __forceinline__ static void put_sz(double* __restrict__ l, int st, const SZ& s) {
+        lds_put_needed(l, st, s, need_sz3);
+    }
+    __device__ __forceinline__ static void get_sz(const double* __restrict__ l, int st, SZ& s) {
+        lds_get_needed(l, st, s, need_sz3);
+    }
 };
 
 struct MathFast3 {
@@ -259,6 +324,8 @@ struct MathFast3 {
     using SX = ShareX3F;
     using SY = ShareY3F;
     using SZ = ShareZ3F;
+    static constexpr int NSY = sizeof(SY) / sizeof(double), NSZ = sizeof(SZ) / sizeof(double);
+    static constexpr bool OWN_FROM_LDS = false;
     static constexpr const char* name = "fast";
     __device__ __forceinline__ static double own(const PA& a, int which) {
         return which == 3 ? a.phi[E3_DYE] : a.phi[E3_U + which];
@@ -270,6 +337,10 @@ struct MathFast3 {
                                                   const SY& YP, const SY& YM, const SZ& ZP, const SZ& ZM, double* o) {
         phaseB3f(K, C, XP, XM, YP, YM, ZP, ZM, o);
     }
+    __device__ __forceinline__ static void put_sy(double* __restrict__ l, int st, const SY& s) { lds_put(l, st, s); }
+    __device__ __forceinline__ static void get_sy(const double* __restrict__ l, int st, SY& s) { lds_get(l, st, s); }
+    __device__ __forceinline__ static void put_sz(double* __restrict__ l, int st, const SZ& s) { lds_put(l, st, s); }
+    __device__ __forceinline__ static void get_sz(const double* __restrict__ l, int st, SZ& s) { lds_get(l, st, s); }
 };
 
 // General 3-D sweep, one thread per cell (lanes along z, then y).  Each thread evaluates phase A
@@ -1011,24 +1082,6 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     }
 }
 
-// A struct of doubles to / from a strided LDS column.
-template <class S>
-__device__ __forceinline__ void lds_put(double* __restrict__ l, int st, const S& s) {
-    constexpr int N = sizeof(S) / sizeof(double);
-    double v[N];
-    __builtin_memcpy(v, &s, sizeof(S));
-#pragma unroll
-    for (int i = 0; i < N; ++i) l[i * st] = v[i];
-}
-template <class S>
-__device__ __forceinline__ void lds_get(const double* __restrict__ l, int st, S& s) {
-    constexpr int N = sizeof(S) / sizeof(double);
-    double v[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = l[i * st];
-    __builtin_memcpy(&s, v, sizeof(S));
-}
-
 // Tiled 3-D sweep.  A block owns a (TY-2) x (TZ-2) patch of (y, z) columns plus a one-cell halo
 // ring (lanes run along z, the contiguous index) and walks a chunk of x-planes.  As in the 2-D
 // tiled kernel each thread keeps its column's stored values and phase-A results for three
@@ -1038,17 +1091,18 @@ __device__ __forceinline__ void lds_get(const double* __restrict__ l, int st, S&
 // values, barrier, writes of row j's products and row j+1's stored values, barrier).  Halo
 // threads have no neighbour on their outer side and use their own value there: what they publish
 // towards the patch does not depend on the slopes along that direction, and they store nothing.
-// LDS (dynamic): NF3 + |SY| + |SZ| doubles per thread.
+// LDS (dynamic): NF3 + NSY + NSZ doubles per thread (+ 4 * NE3 where the policy parks left-hand sides there).
 template <class M, int TY, int TZ, int MINW>
 __global__ void __launch_bounds__(TY * TZ, MINW)
 sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
               const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi, int ch) {
     constexpr int NT = TY * TZ;
-    constexpr int NSY = sizeof(typename M::SY) / sizeof(double);
+    constexpr int NSY = M::NSY;
     extern __shared__ double smem[];
     double* const lraw = smem;                      // [NF3][NT]
     double* const lsy = smem + NF3 * NT;            // [NSY][NT]
     double* const lsz = lsy + NSY * NT;             // [NSZ][NT]
+    double* const lown = lsz + M::NSZ * NT;         // [2][2 * NE3][NT], OWN_FROM_LDS only: see row()
     const int t = threadIdx.x, tz = t % TZ, ty = t / TZ;
     const int zbase = (int)blockIdx.x * (TZ - 2) - 1, ybase = (int)blockIdx.y * (TY - 2) - 1;
     const int y = ybase + ty, z = zbase + tz;
@@ -1082,23 +1136,52 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     typename M::PA P0, P1, P2;
     unsigned char act_c = 1;
 
-    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XP, const typename M::SX& XM) {
+    // kept[]: OWN_FROM_LDS only -- the stored U, V, W, Dye of the row, fetched by row() for the inactive lanes
+    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XP, const typename M::SX& XM,
+                    const double kept[4]) {
         typename M::SY YP, YM;
         typename M::SZ ZP, ZM;
-        lds_get(lsy + lN, NT, YP);
-        lds_get(lsy + lS, NT, YM);
-        lds_get(lsz + lT, NT, ZP);
-        lds_get(lsz + lB, NT, ZM);
+        M::get_sy(lsy + lN, NT, YP);
+        M::get_sy(lsy + lS, NT, YM);
+        M::get_sz(lsz + lT, NT, ZP);
+        M::get_sz(lsz + lB, NT, ZM);
         double o[NE3];
-        M::phaseB(K, C, XP, XM, YP, YM, ZP, ZM, o);
+        if constexpr (M::OWN_FROM_LDS) {
+            // the cell's own y / z products are still in LDS, and row() has parked its left-hand sides and
+            // coefficients there: read them back instead of carrying them in registers for a row
+            typename M::PA Cl = C;
+            M::get_sy(lsy + t, NT, Cl.sy);
+            M::get_sz(lsz + t, NT, Cl.sz);
+            const double* lp = lown + (size_t)(x & 1) * (2 * NE3 * NT) + t;
+#pragma unroll
+            for (int e = 0; e < NE3; ++e) {
+                Cl.lhs[e] = lp[e * NT];
+                Cl.aU[e] = lp[(NE3 + e) * NT];
+            }
+            M::phaseB(K, Cl, XP, XM, YP, YM, ZP, ZM, o);
+        } else {
+            M::phaseB(K, C, XP, XM, YP, YM, ZP, ZM, o);
+        }
         const lane_mask am = mask_of(act_c != 0);
         const PlaneRef d(dst + (long)x * plane6, pbytes);
         d.st(vst, (unsigned)F3_RHO * fstride, o[E3_RHO]);
         d.st(vst, (unsigned)F3_T * fstride, o[E3_T]);
-        d.st(vst, (unsigned)F3_U * fstride, select(am, o[E3_U], M::own(C, 0)));
-        d.st(vst, (unsigned)F3_V * fstride, select(am, o[E3_V], M::own(C, 1)));
-        d.st(vst, (unsigned)F3_W * fstride, select(am, o[E3_W], M::own(C, 2)));
-        d.st(vst, (unsigned)F3_DYE * fstride, select(am, o[E3_DYE], M::own(C, 3)));
+        auto own = [&](int i) { if constexpr (M::OWN_FROM_LDS) return kept[i]; else return M::own(C, i); };
+        d.st(vst, (unsigned)F3_U * fstride, select(am, o[E3_U], own(0)));
+        d.st(vst, (unsigned)F3_V * fstride, select(am, o[E3_V], own(1)));
+        d.st(vst, (unsigned)F3_W * fstride, select(am, o[E3_W], own(2)));
+        d.st(vst, (unsigned)F3_DYE * fstride, select(am, o[E3_DYE], own(3)));
+    };
+    // stored U, V, W, Dye of row x for the lanes whose cell is inactive there (the others fetch nothing)
+    auto load_kept = [&](int x, double kept[4]) {
+        if constexpr (M::OWN_FROM_LDS) {
+            const PlaneRef p(src + (long)x * plane6, pbytes);
+            const unsigned v = act_c != 0 ? 0xFFFFFFF0u : vc;
+            kept[0] = p.ld(v, (unsigned)F3_U * fstride);
+            kept[1] = p.ld(v, (unsigned)F3_V * fstride);
+            kept[2] = p.ld(v, (unsigned)F3_W * fstride);
+            kept[3] = p.ld(v, (unsigned)F3_DYE * fstride);
+        }
     };
     // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw holds row j of every thread, lsy / lsz
     // the products of row j-1.
@@ -1109,19 +1192,30 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         for (int f = 0; f < NF3; ++f) h[0][f] = half_slope(Re[f], Rc[f], Rw[f]);
         load_row(clampx(j + 2), Rw);        // Rw is dead: fetch row j+2 into it
         const unsigned char act_n = load_act(j);
+        double kept[4];
+        if (!first && j - 1 >= xs) load_kept(j - 1, kept);
 #pragma unroll
         for (int f = 0; f < NF3; ++f) {
             h[1][f] = half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS]);
             h[2][f] = half_slope(lraw[f * NT + lT], Rc[f], lraw[f * NT + lB]);
         }
         M::phaseA(K, Rc, h, An);
+        if constexpr (M::OWN_FROM_LDS) {
+            // this thread's own slot, two rows deep: no other thread reads it, so no barrier is involved
+            double* lp = lown + (size_t)(j & 1) * (2 * NE3 * NT) + t;
+#pragma unroll
+            for (int e = 0; e < NE3; ++e) {
+                lp[e * NT] = An.lhs[e];
+                lp[(NE3 + e) * NT] = An.aU[e];
+            }
+        }
         const int x = j - 1;
-        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx);       // block-uniform
+        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, kept);       // block-uniform
         __syncthreads();
 #pragma unroll
         for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = Re[f];
-        lds_put(lsy + t, NT, An.sy);
-        lds_put(lsz + t, NT, An.sz);
+        M::put_sy(lsy + t, NT, An.sy);
+        M::put_sz(lsz + t, NT, An.sz);
         __syncthreads();
         act_c = act_n;
     };
@@ -1146,9 +1240,11 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     }
     // last owned row of the domain: its clamped East neighbour is the cell itself
     if (j1 < xe) {
-        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx);
-        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx);
-        else emit(xe - 1, P2, P2.sx, P1.sx);
+        double kept[4];
+        load_kept(xe - 1, kept);
+        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx, kept);
+        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, kept);
+        else emit(xe - 1, P2, P2.sx, P1.sx, kept);
     }
 }
 
@@ -1544,8 +1640,7 @@ static int scratch_setup(int device) {
 // support it; *did_fuse tells the caller whether it happened).
 template <class M>
 static size_t march3_lds_bytes(int nt) {
-    return (size_t)(NF3 + sizeof(typename M::SY) / sizeof(double) + sizeof(typename M::SZ) / sizeof(double)) * nt *
-           sizeof(double);
+    return (size_t)(NF3 + M::NSY + M::NSZ + (M::OWN_FROM_LDS ? 4 * NE3 : 0)) * nt * sizeof(double);
 }
 
 // x0, x1: the range of owned x-planes to compute (x1 < 0: all of them).
@@ -1661,7 +1756,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
 #undef LAUNCH_MARCH2W
 #undef LAUNCH_STREAM
 #undef LAUNCH_STREAM_RD
-    } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant < 0)) {
+    } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok) {
         dim3 block(64), grid((unsigned)((h->plane + 63) / 64), x1 - x0);
         if (fast)
             hipExtLaunchKernelGGL(sweep3d_simple<MathFast3>, grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
@@ -1722,6 +1817,11 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
             switch (h->variant < 0 ? 0 : h->variant) {
                 case 1: LAUNCH_MARCH3(MathStrict3, h->K, 8, 32, 1); break;
                 case 3: LAUNCH_MARCH3(MathStrict3, h->K, 8, 16, 1); break;
+                case 9:         // the per-cell kernel
+                    hipExtLaunchKernelGGL(sweep3d_simple<MathStrict3>, dim3((unsigned)((h->plane + 63) / 64), x1 - x0),
+                                          dim3(64), 0, h->stream, ea, eb, 0, h->K, src, dst, act, x0, x1, p.ny, p.nz,
+                                          xlo, xhi);
+                    break;
                 default: LAUNCH_MARCH3(MathStrict3, h->K, 16, 16, 1); break;
             }
         }
@@ -2304,9 +2404,7 @@ const char* cfd_kernel_name(cfd_handle* h) {
     if (!h) return "";
     const bool fast = (h->p.flags & CFD_FLAG_FAST_MATH) != 0;
     if (!h->two_d) {
-        // strict 3-D: the tiled kernel spills with the strict form's larger product sets and is the
-        // slower one; it runs only when a launch shape is asked for explicitly
-        if ((h->p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant < 0))
+        if ((h->p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant == 9))
             return fast ? "sweep3d_simple<fast>" : "sweep3d_simple<strict>";
         if (fast && (h->variant < 1 || h->variant > 5)) return "sweep3d_stream<fast>";
         return fast ? "sweep3d_march<fast>" : "sweep3d_march<strict>";

@@ -41,7 +41,7 @@ def _assert_slots_bit_equal(g, b, what):
                                                 ((37, 254), 9, False), ((33, 255), 10, False),
                                                 ((9, 509), 11, False)])
 @pytest.mark.parametrize("flags,chunk,variant", [(1, 32, 8), (0, 32, 12), (0, 1, 13), (0, 5, 14), (0, 32, 8), (0, 1, 8),
-                                                 (0, 4, 12), (0, 7, 0)])
+                                                 (0, 4, 12), (0, 7, 0), (0, 32, -1), (0, 1, -1)])
 def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags, chunk, variant, monkeypatch):
     monkeypatch.setenv("CFD_CHUNK", str(chunk))
     monkeypatch.setenv("CFD_VARIANT", str(variant))
@@ -49,6 +49,7 @@ def test_sweeps_bit_exact_2d(shape, seed, zero_v, flags, chunk, variant, monkeyp
     g = _gpu_graph(params, fields, active, flags)
     b = _oracle(params, fields, active, pow_mode=1)
     assert g.live_fields == 5
+    assert g.kernel_name() == ("sweep2d_simple<strict>" if flags & 1 else "sweep2d_march2<strict>")
     for i, st in enumerate([True, False, False, True, False]):
         g.sweep(st)
         b.sweep(st)
@@ -410,15 +411,15 @@ def test_slab_pair_needs_masks_and_two_planes():
         assert e.value.code == -4 and "slab" in str(e.value)
 
 
-@pytest.mark.parametrize("kernel,chunk,variant", [(1, 32, -1), (0, 32, 0), (0, 1, 0), (0, 3, 0), (0, 32, 1),
-                                                   (0, 4, 3)])
+@pytest.mark.parametrize("kernel,chunk,variant", [(1, 32, -1), (0, 32, -1), (0, 1, 0), (0, 3, 0), (0, 32, 1),
+                                                   (0, 4, 3), (0, 5, 2), (0, 32, 9)])
 @pytest.mark.parametrize("shape,seed,zero_v,flags", [((7, 6, 5), 1, False, 0), ((3, 3, 3), 2, True, 0),
                                                       ((12, 9, 1), 3, False, 2), ((4, 1, 70), 4, False, 0),
                                                       ((1, 1, 1), 5, False, 2), ((9, 20, 13), 6, True, 0),
                                                       ((20, 3, 1), 7, False, 0), ((5, 31, 30), 8, False, 0),
                                                       ((40, 15, 29), 9, False, 0)])
 def test_sweeps_bit_exact_3d(shape, seed, zero_v, flags, kernel, chunk, variant, monkeypatch):
-    """General 3-D kernels, per-cell (kernel=1) and tiled in several launch shapes and chunk lengths
+    """General 3-D kernels, per-cell (kernel=1, variant 9) and tiled in several launch shapes and chunk lengths
     (also reached with nz == 1 when W != 0 or when forced): bit-exact against Oracle B over sweeps
     and full steps.  The shapes straddle tile edges (14 and 30 interior columns per tile side)."""
     monkeypatch.setenv("CFD_CHUNK", str(chunk))
@@ -429,7 +430,8 @@ def test_sweeps_bit_exact_3d(shape, seed, zero_v, flags, kernel, chunk, variant,
     g = _gpu_graph(params, fields, active, flags | kernel)
     b = _oracle(params, fields, active, pow_mode=1)
     assert g.live_fields == 6
-    assert g.kernel_name() == ("sweep3d_simple<strict>" if kernel else "sweep3d_march<strict>")
+    # strict default: the tiled kernel; the per-cell one on request
+    assert g.kernel_name() == ("sweep3d_simple<strict>" if kernel or variant == 9 else "sweep3d_march<strict>")
     for i, st in enumerate([True, False, False]):
         g.sweep(st)
         b.sweep(st)
