@@ -167,6 +167,7 @@ struct MathStrict2 {
     using SX = ShareX2;
     using SY = ShareY2;
     static constexpr int NSY = 12;
+    static constexpr bool OWN_FROM_LDS = true;      // phase B re-reads the cell's own y products from LDS
     // stored U, V, Dye of the cell (which = 0, 1, 2)
     __device__ __forceinline__ static double own(const PA& a, int which) { return a.own[which]; }
     __device__ __forceinline__ static void phaseA(const Consts& K, const double* c, const double* hx,
@@ -195,6 +196,7 @@ struct MathFast2 {
     using SX = ShareXF;
     using SY = ShareYF;
     static constexpr int NSY = 6;
+    static constexpr bool OWN_FROM_LDS = false;
     __device__ __forceinline__ static double own(const PA& a, int which) {
         return which == 0 ? a.phi[E2_U] : (which == 1 ? a.phi[E2_V] : a.phi[E2_DYE]);
     }
@@ -477,6 +479,9 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
                const double* __restrict__ fpp, double* __restrict__ fprev) {
     __shared__ double lds[2][M::NSY][NT];
     __shared__ double lraw[2][NF2][NT];
+    // OWN_FROM_LDS: a thread's private slot, two rows deep, for the left-hand sides and coefficients of the
+    // row it has evaluated but not yet finished (instead of carrying them in registers for a row)
+    __shared__ double lown[2][10][M::OWN_FROM_LDS ? NT : 1];
     const int t = threadIdx.x;
     // Lanes 0 .. WCOLS-1 hold the block's own columns in order (with WCOLS a multiple of 16 every
     // wave's store covers whole 128-byte lines), lane WCOLS the column above the tile, lane WCOLS+1
@@ -526,17 +531,30 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
             for (int f = 0; f < NF2; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
         }
     };
+    // kept[]: OWN_FROM_LDS only -- the stored U, V, Dye of the row, fetched by row() for the inactive lanes
     auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW,
-                    const double pp[NF2]) {
+                    const double pp[NF2], const double kept[3]) {
         typename M::SY YN, YS;
         M::get_sy(&lds[x & 1][0][lnc], NT, YN);
         M::get_sy(&lds[x & 1][0][lsc], NT, YS);
         double o[5];
-        M::phaseB(K, C, XE, XW, YN, YS, o);
+        if constexpr (M::OWN_FROM_LDS) {
+            typename M::PA Cl = C;
+            M::get_sy(&lds[x & 1][0][t], NT, Cl.sy);
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                Cl.lhs[e] = lown[x & 1][e][t];
+                Cl.aU[e] = lown[x & 1][5 + e][t];
+            }
+            M::phaseB(K, Cl, XE, XW, YN, YS, o);
+        } else {
+            M::phaseB(K, C, XE, XW, YN, YS, o);
+        }
         const bool act = act_c != 0;
         const lane_mask am = mask_of(act);
-        const double nU = select(am, o[E2_U], M::own(C, 0)), nV = select(am, o[E2_V], M::own(C, 1)),
-                     nD = select(am, o[E2_DYE], M::own(C, 2));
+        auto own = [&](int i) { if constexpr (M::OWN_FROM_LDS) return kept[i]; else return M::own(C, i); };
+        const double nU = select(am, o[E2_U], own(0)), nV = select(am, o[E2_V], own(1)),
+                     nD = select(am, o[E2_DYE], own(2));
         const PlaneRef d(dst + (long)x * plane5, pbytes);
         d.st_nt(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
         d.st_nt(vst, (unsigned)F2_T * fstride, o[E2_T]);
@@ -554,14 +572,24 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
             pv.st_nt(vm, (unsigned)F2_DYE * fstride, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])));
         }
     };
+    // stored U, V, Dye of row x for the lanes whose cell is inactive there (the others fetch nothing)
+    auto load_kept = [&](int x, double kept[3]) {
+        if constexpr (M::OWN_FROM_LDS) {
+            const PlaneRef p(src + (long)x * plane5, pbytes);
+            const unsigned v = act_c != 0 ? 0xFFFFFFF0u : vc;
+            kept[0] = p.ld(v, (unsigned)F2_U * fstride);
+            kept[1] = p.ld(v, (unsigned)F2_V * fstride);
+            kept[2] = p.ld(v, (unsigned)F2_DYE * fstride);
+        }
+    };
     // Row j: Rw, Rc, Re hold rows j-1, j, j+1 (clamped); lraw[j&1] holds row j of every lane.
     auto row = [&](int j, double* Rw, const double* Rc, const double* Re, typename M::PA& An,
                    const typename M::PA& Ac, const typename M::PA& Aw, bool first) {
-        double hx[NF2], pp[NF2];
+        double hx[NF2], pp[NF2], kept[3];
         x_half_slopes2(Rc, Re, Rw, hx);
         // Rw is dead: fetch row j+2 into it; also this row's mask
         load_row(clampx(j + 2), vc, Rw);
-        if (!first && j - 1 >= xs) load_pp(j - 1, pp);
+        if (!first && j - 1 >= xs) { load_pp(j - 1, pp); load_kept(j - 1, kept); }
         const unsigned char act_n = load_act(j);
 #pragma unroll
         for (int f = 0; f < NF2; ++f) lraw[(j + 1) & 1][f][t] = Re[f];
@@ -573,8 +601,15 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         }
         M::phaseA(K, Rc, hx, rn, rs, An);
         M::put_sy(&lds[j & 1][0][t], NT, An.sy);
+        if constexpr (M::OWN_FROM_LDS) {
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                lown[j & 1][e][t] = An.lhs[e];
+                lown[j & 1][5 + e][t] = An.aU[e];
+            }
+        }
         const int x = j - 1;
-        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, pp);   // block-uniform
+        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, pp, kept);   // block-uniform
         __syncthreads();
         act_c = act_n;
     };
@@ -598,11 +633,12 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         row(j, R0, R1, R2, P0, P2, P1, false); ++j;
     }
     if (j1 < xe) {
-        double pp[NF2];
+        double pp[NF2], kept[3];
         load_pp(xe - 1, pp);
-        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx, pp);
-        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, pp);
-        else emit(xe - 1, P2, P2.sx, P1.sx, pp);
+        load_kept(xe - 1, kept);
+        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx, pp, kept);
+        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, pp, kept);
+        else emit(xe - 1, P2, P2.sx, P1.sx, pp, kept);
     }
 }
 

@@ -42,11 +42,16 @@ struct SweepConsts {
     double Hx, Hy, Hz;      // 2 * average [h, h_n1, h_n2] (cross-direction interval)
     double rhx, rhy, rhz;   // correctly rounded reciprocals of the six intervals (for div_by)
     double rHx, rHy, rHz;
+    double lhx, lhy, lhz;   // and their low parts: RN(1/h - rh), so that rh + lh is 1/h to about 106 bits
+    double lHx, lHy, lHz;
     double lambda, suth, R, cv, k, dyef;
     double m23;             // -(2/3)
     double c83h;            // (8/3)/2
     double c83n;            // (8/3)*(-1)
 };
+
+// Low part of the reciprocal of h, given rh = RN(1/h): (1 - rh h) / h, whose numerator fma forms exactly.
+inline double recip_low(double h, double rh) { return fma(-rh, h, 1.0) / h; }
 
 // Host-side construction in the reference's fold orders (avMap/slMap, average).
 inline SweepConsts make_consts(double dx, double dy, double dz, double dt, double lambda,
@@ -67,6 +72,8 @@ inline SweepConsts make_consts(double dx, double dy, double dz, double dt, doubl
     c.Hx = hc[0]; c.Hy = hc[1]; c.Hz = hc[2];
     c.rhx = 1.0 / c.hx; c.rhy = 1.0 / c.hy; c.rhz = 1.0 / c.hz;
     c.rHx = 1.0 / c.Hx; c.rHy = 1.0 / c.Hy; c.rHz = 1.0 / c.Hz;
+    c.lhx = recip_low(c.hx, c.rhx); c.lhy = recip_low(c.hy, c.rhy); c.lhz = recip_low(c.hz, c.rhz);
+    c.lHx = recip_low(c.Hx, c.rHx); c.lHy = recip_low(c.Hy, c.rHy); c.lHz = recip_low(c.Hz, c.rHz);
     c.lambda = lambda; c.suth = suth; c.R = R; c.cv = cv; c.k = k; c.dyef = dyef;
     c.m23 = -(2.0 / 3.0);
     c.c83h = (8.0 / 3.0) / 2.0;
@@ -119,19 +126,20 @@ CFD_HD double half_slope(double up, double vc, double lo) {
     return half_superbee(up - vc, vc - lo);
 }
 
-// x / h, correctly rounded, for a divisor h that is known in advance with rh = RN(1/h):
-// two Newton corrections with exact (fused) residuals.  After the first, q is within one ulp of
-// x/h; with a correctly rounded reciprocal the second then lands on the correctly rounded quotient
-// (Markstein's theorem), i.e. the same bits as the IEEE division the reference performs, at 5
-// multiply-add operations instead of the ~12-instruction division sequence.  Holds for finite x
-// with |x| >= 2^-970 or x == 0 (below that the residuals underflow and are no longer exact); a zero
-// quotient may lose its sign.  The numerators it is used on are differences of viscous /
-// conductive products of velocity and temperature scale; the Dye terms, whose numerators do
-// decay into that range, use the plain division.
-CFD_HD double div_by(double x, double h, double rh) {
-    const double q0 = x * rh;
-    const double q1 = fma(fma(-q0, h, x), rh, q0);
-    return fma(fma(-q1, h, x), rh, q1);
+// x / h, correctly rounded, for a divisor h that is known in advance, with rh = RN(1/h) and rl = RN(1/h - rh).
+//   q0 = x rh + RN(x rl)   one rounding of a product taken with a 106-bit reciprocal: within half an ulp (and a
+//                          2^-50 ulp) of x/h, i.e. a faithful quotient;
+//   r  = x - q0 h          exact in one fused multiply-add, because q0 is faithful;
+//   q  = q0 + r rh         Markstein's theorem: a faithful quotient corrected once with the exact residual and the
+//                          correctly rounded reciprocal is the correctly rounded quotient --
+// the same bits as the IEEE division the reference performs, in 4 multiply-add operations instead of the
+// ~12-instruction division sequence.  Holds for finite x with |x| >= 2^-970 or x == 0 (below that the residual
+// underflows and is no longer exact); a zero quotient may lose its sign.  The numerators it is used on are
+// differences of viscous / conductive products of velocity and temperature scale; the Dye terms, whose
+// numerators do decay into that range, use the plain division.
+CFD_HD double div_by(double x, double h, double rh, double rl) {
+    const double q0 = fma(x, rh, x * rl);
+    return fma(fma(-q0, h, x), rh, q0);
 }
 
 CFD_HD double mu_of(const SweepConsts& k, double t) {
@@ -360,48 +368,48 @@ CFD_HD void phaseB2(const SweepConsts& k, const PhaseA2& C, const ShareX2& XE, c
 
     // ---- U momentum
     {
-        const double d1u = div_by(XE.aX - X.aX, hx, k.rhx), d1l = div_by(XW.aX - X.aX, hx, k.rhx);   // d/dx(d(mu U)/dx)
+        const double d1u = div_by(XE.aX - X.aX, hx, k.rhx, k.lhx), d1l = div_by(XW.aX - X.aX, hx, k.rhx, k.lhx);   // d/dx(d(mu U)/dx)
         r = 0.0 + d1u;  r = r + d1l;
-        r = r + div_by(YN.aY - Y.aY, hy, k.rhy);   r = r + div_by(YS.aY - Y.aY, hy, k.rhy);           // d/dy(d(mu U)/dy)
+        r = r + div_by(YN.aY - Y.aY, hy, k.rhy, k.lhy);   r = r + div_by(YS.aY - Y.aY, hy, k.rhy, k.lhy);           // d/dy(d(mu U)/dy)
         r = r + d1u;    r = r + d1l;                                           // d/dx(d(mu U)/dx) again
-        r = r + div_by(XE.bN - XW.bN, Hx, k.rHx);  r = r + div_by(XW.bS - XE.bS, Hx, k.rHx);           // d/dy(d(mu V)/dx)
-        r = r + div_by(XE.aX23 - X.aX23, hx, k.rhx);  r = r + div_by(XW.aX23 - X.aX23, hx, k.rhx);     // -2/3 d/dx(d(mu U)/dx)
-        r = r + div_by(YN.bE23 - YS.bE23, Hy, k.rHy); r = r + div_by(YS.bW23 - YN.bW23, Hy, k.rHy);    // -2/3 d/dx(d(mu V)/dy)
+        r = r + div_by(XE.bN - XW.bN, Hx, k.rHx, k.lHx);  r = r + div_by(XW.bS - XE.bS, Hx, k.rHx, k.lHx);           // d/dy(d(mu V)/dx)
+        r = r + div_by(XE.aX23 - X.aX23, hx, k.rhx, k.lhx);  r = r + div_by(XW.aX23 - X.aX23, hx, k.rhx, k.lhx);     // -2/3 d/dx(d(mu U)/dx)
+        r = r + div_by(YN.bE23 - YS.bE23, Hy, k.rHy, k.lHy); r = r + div_by(YS.bW23 - YN.bW23, Hy, k.rHy, k.lHy);    // -2/3 d/dx(d(mu V)/dy)
         out[E2_U] = (r - C.lhs[E2_U]) / C.aU[E2_U];
     }
     // ---- V momentum
     {
-        const double d2u = div_by(YN.bY - Y.bY, hy, k.rhy), d2l = div_by(YS.bY - Y.bY, hy, k.rhy);   // d/dy(d(mu V)/dy)
-        r = 0.0 + div_by(XE.bX - X.bX, hx, k.rhx);  r = r + div_by(XW.bX - X.bX, hx, k.rhx);           // d/dx(d(mu V)/dx)
+        const double d2u = div_by(YN.bY - Y.bY, hy, k.rhy, k.lhy), d2l = div_by(YS.bY - Y.bY, hy, k.rhy, k.lhy);   // d/dy(d(mu V)/dy)
+        r = 0.0 + div_by(XE.bX - X.bX, hx, k.rhx, k.lhx);  r = r + div_by(XW.bX - X.bX, hx, k.rhx, k.lhx);           // d/dx(d(mu V)/dx)
         r = r + d2u;    r = r + d2l;
-        r = r + div_by(YN.aE - YS.aE, Hy, k.rHy);   r = r + div_by(YS.aW - YN.aW, Hy, k.rHy);          // d/dx(d(mu U)/dy)
+        r = r + div_by(YN.aE - YS.aE, Hy, k.rHy, k.lHy);   r = r + div_by(YS.aW - YN.aW, Hy, k.rHy, k.lHy);          // d/dx(d(mu U)/dy)
         r = r + d2u;    r = r + d2l;                                           // d/dy(d(mu V)/dy) again
-        r = r + div_by(XE.aN23 - XW.aN23, Hx, k.rHx);  r = r + div_by(XW.aS23 - XE.aS23, Hx, k.rHx);   // -2/3 d/dy(d(mu U)/dx)
-        r = r + div_by(YN.bY23 - Y.bY23, hy, k.rhy);   r = r + div_by(YS.bY23 - Y.bY23, hy, k.rhy);    // -2/3 d/dy(d(mu V)/dy)
+        r = r + div_by(XE.aN23 - XW.aN23, Hx, k.rHx, k.lHx);  r = r + div_by(XW.aS23 - XE.aS23, Hx, k.rHx, k.lHx);   // -2/3 d/dy(d(mu U)/dx)
+        r = r + div_by(YN.bY23 - Y.bY23, hy, k.rhy, k.lhy);   r = r + div_by(YS.bY23 - Y.bY23, hy, k.rhy, k.lhy);    // -2/3 d/dy(d(mu V)/dy)
         out[E2_V] = (r - C.lhs[E2_V]) / C.aU[E2_V];
     }
     // ---- energy
     {
-        r = 0.0 + div_by(XE.tX - X.tX, hx, k.rhx);  r = r + div_by(XW.tX - X.tX, hx, k.rhx);           // k lap(T), x
-        r = r + div_by(YN.tY - Y.tY, hy, k.rhy);    r = r + div_by(YS.tY - Y.tY, hy, k.rhy);           // k lap(T), y
+        r = 0.0 + div_by(XE.tX - X.tX, hx, k.rhx, k.lhx);  r = r + div_by(XW.tX - X.tX, hx, k.rhx, k.lhx);           // k lap(T), x
+        r = r + div_by(YN.tY - Y.tY, hy, k.rhy, k.lhy);    r = r + div_by(YS.tY - Y.tY, hy, k.rhy, k.lhy);           // k lap(T), y
         // squareDerivative [Mew,U] (8/3) X
-        r = r + div_by(XE.a2X83 - X.a2X83, hx, k.rhx);  r = r + div_by(XW.a2X83 - X.a2X83, hx, k.rhx);
-        r = r + div_by(XE.aX83 - X.aX83, hx, k.rhx);    r = r + div_by(XW.aX83 - X.aX83, hx, k.rhx);
+        r = r + div_by(XE.a2X83 - X.a2X83, hx, k.rhx, k.lhx);  r = r + div_by(XW.a2X83 - X.a2X83, hx, k.rhx, k.lhx);
+        r = r + div_by(XE.aX83 - X.aX83, hx, k.rhx, k.lhx);    r = r + div_by(XW.aX83 - X.aX83, hx, k.rhx, k.lhx);
         // squareDerivative [Mew,V] (8/3) Y
-        r = r + div_by(YN.b2Y83 - Y.b2Y83, hy, k.rhy);  r = r + div_by(YS.b2Y83 - Y.b2Y83, hy, k.rhy);
-        r = r + div_by(YN.bY83 - Y.bY83, hy, k.rhy);    r = r + div_by(YS.bY83 - Y.bY83, hy, k.rhy);
+        r = r + div_by(YN.b2Y83 - Y.b2Y83, hy, k.rhy, k.lhy);  r = r + div_by(YS.b2Y83 - Y.b2Y83, hy, k.rhy, k.lhy);
+        r = r + div_by(YN.bY83 - Y.bY83, hy, k.rhy, k.lhy);    r = r + div_by(YS.bY83 - Y.bY83, hy, k.rhy, k.lhy);
         // squareDerivative [Mew,U] 1 Y   (second term has factor -1: differences flip)
-        r = r + div_by(YN.a2Yh - Y.a2Yh, hy, k.rhy);    r = r + div_by(YS.a2Yh - Y.a2Yh, hy, k.rhy);
-        r = r + div_by(Y.aY - YN.aY, hy, k.rhy);        r = r + div_by(Y.aY - YS.aY, hy, k.rhy);
+        r = r + div_by(YN.a2Yh - Y.a2Yh, hy, k.rhy, k.lhy);    r = r + div_by(YS.a2Yh - Y.a2Yh, hy, k.rhy, k.lhy);
+        r = r + div_by(Y.aY - YN.aY, hy, k.rhy, k.lhy);        r = r + div_by(Y.aY - YS.aY, hy, k.rhy, k.lhy);
         // squareDerivative [Mew,V] 1 X
-        r = r + div_by(XE.b2Xh - X.b2Xh, hx, k.rhx);    r = r + div_by(XW.b2Xh - X.b2Xh, hx, k.rhx);
-        r = r + div_by(X.bX - XE.bX, hx, k.rhx);        r = r + div_by(X.bX - XW.bX, hx, k.rhx);
+        r = r + div_by(XE.b2Xh - X.b2Xh, hx, k.rhx, k.lhx);    r = r + div_by(XW.b2Xh - X.b2Xh, hx, k.rhx, k.lhx);
+        r = r + div_by(X.bX - XE.bX, hx, k.rhx, k.lhx);        r = r + div_by(X.bX - XW.bX, hx, k.rhx, k.lhx);
         // pairedMultipliedDerivatives [Mew,U] [V] X Y
-        r = r + div_by(XE.cN - XW.cN, Hx, k.rHx);       r = r + div_by(XW.cS - XE.cS, Hx, k.rHx);
-        r = r + div_by(XW.aN - XE.aN, Hx, k.rHx);       r = r + div_by(XE.aS - XW.aS, Hx, k.rHx);
-        r = r + div_by(XW.vN - XE.vN, Hx, k.rHx);       r = r + div_by(XE.vS - XW.vS, Hx, k.rHx);
+        r = r + div_by(XE.cN - XW.cN, Hx, k.rHx, k.lHx);       r = r + div_by(XW.cS - XE.cS, Hx, k.rHx, k.lHx);
+        r = r + div_by(XW.aN - XE.aN, Hx, k.rHx, k.lHx);       r = r + div_by(XE.aS - XW.aS, Hx, k.rHx, k.lHx);
+        r = r + div_by(XW.vN - XE.vN, Hx, k.rHx, k.lHx);       r = r + div_by(XE.vS - XW.vS, Hx, k.rHx, k.lHx);
         // pairedMultipliedDerivatives [Mew,U] [W] X Z: the surviving +X, -X pair
-        const double zl = div_by(XW.aZ - XE.aZ, Hx, k.rHx);
+        const double zl = div_by(XW.aZ - XE.aZ, Hx, k.rHx, k.lHx);
         r = r + zl;                         r = r - zl;
         out[E2_T] = (r - C.lhs[E2_T]) / C.aU[E2_T];
     }
@@ -932,13 +940,14 @@ CFD_HD void phaseB3(const SweepConsts& k, const PhaseA3& C, const ShareX3& XP, c
                     const ShareY3& YP, const ShareY3& YM, const ShareZ3& ZP, const ShareZ3& ZM, double out[NE3]) {
     const double hx = k.hx, hy = k.hy, hz = k.hz, Hx = k.Hx, Hy = k.Hy, Hz = k.Hz;
     const double rhx = k.rhx, rhy = k.rhy, rhz = k.rhz, rHx = k.rHx, rHy = k.rHy, rHz = k.rHz;
+    const double lhx = k.lhx, lhy = k.lhy, lhz = k.lhz, lHx = k.lHx, lHy = k.lHy, lHz = k.lHz;
     const SameDir3 &cx = C.sx.s, &cy = C.sy.s, &cz = C.sz.s;
     const SameDir3 &xp = XP.s, &xm = XM.s, &yp = YP.s, &ym = YM.s, &zp = ZP.s, &zm = ZM.s;
     double r;
-#define SAME(r, up, lo, cc, h)   do { (r) = (r) + div_by((up) - (cc), h, r##h); (r) = (r) + div_by((lo) - (cc), h, r##h); } while (0)
-#define SAMEN(r, up, lo, cc, h)  do { (r) = (r) + div_by((cc) - (up), h, r##h); (r) = (r) + div_by((cc) - (lo), h, r##h); } while (0)
-#define CROSS(r, n1, n2, fld, H)  do { (r) = (r) + div_by((n1).fld[0] - (n2).fld[0], H, r##H); (r) = (r) + div_by((n2).fld[1] - (n1).fld[1], H, r##H); } while (0)
-#define CROSSN(r, n1, n2, fld, H) do { (r) = (r) + div_by((n2).fld[0] - (n1).fld[0], H, r##H); (r) = (r) + div_by((n1).fld[1] - (n2).fld[1], H, r##H); } while (0)
+#define SAME(r, up, lo, cc, h)   do { (r) = (r) + div_by((up) - (cc), h, r##h, l##h); (r) = (r) + div_by((lo) - (cc), h, r##h, l##h); } while (0)
+#define SAMEN(r, up, lo, cc, h)  do { (r) = (r) + div_by((cc) - (up), h, r##h, l##h); (r) = (r) + div_by((cc) - (lo), h, r##h, l##h); } while (0)
+#define CROSS(r, n1, n2, fld, H)  do { (r) = (r) + div_by((n1).fld[0] - (n2).fld[0], H, r##H, l##H); (r) = (r) + div_by((n2).fld[1] - (n1).fld[1], H, r##H, l##H); } while (0)
+#define CROSSN(r, n1, n2, fld, H) do { (r) = (r) + div_by((n2).fld[0] - (n1).fld[0], H, r##H, l##H); (r) = (r) + div_by((n1).fld[1] - (n2).fld[1], H, r##H, l##H); } while (0)
     // ---- continuity
     r = 0.0 + 0.0;
     out[E3_RHO] = (r - C.lhs[E3_RHO]) / C.aU[E3_RHO];

@@ -122,7 +122,7 @@ extern "C" double hm_half_superbee(double a, double b) { return half_superbee(a,
 // Brute-force check of div_by against the IEEE division for n pseudo-random numerators (xorshift,
 // magnitudes spread over 2^-60 .. 2^60); returns the number of mismatching bit patterns.
 extern "C" long hm_div_by_mismatches(double h, long n, unsigned long long seed) {
-    const double rh = 1.0 / h;
+    const double rh = 1.0 / h, rl = recip_low(h, rh);
     unsigned long long s = seed ? seed : 88172645463325252ull;
     long bad = 0;
     for (long i = 0; i < n; ++i) {
@@ -131,7 +131,7 @@ extern "C" long hm_div_by_mismatches(double h, long n, unsigned long long seed) 
         const int e = (int)((s >> 3) % 121) - 60;
         double x = ldexp(mant, e);
         if (s & 1) x = -x;
-        const double a = x / h, b = div_by(x, h, rh);
+        const double a = x / h, b = div_by(x, h, rh, rl);
         if (__builtin_memcmp(&a, &b, 8) != 0) ++bad;
     }
     return bad;

@@ -175,8 +175,10 @@ def test_half_superbee_special_values(hm):
 
 
 def test_div_by_constant_is_correctly_rounded(hm):
-    """div_by (five fused multiply-adds with a correctly rounded reciprocal) against the IEEE division
-    on 2e7 random numerators for each interval constant of several grids: zero mismatches."""
+    """div_by (four multiply-adds with the reciprocal held as a correctly rounded high part and a low part)
+    against the IEEE division on 2e6 random numerators for each interval constant of several grids, for
+    divisors at the edges of a binade (significand all ones, one ulp above a power of two, powers of two)
+    and for random divisors: zero mismatches."""
     hm.hm_div_by_mismatches.restype = ctypes.c_long
     hm.hm_div_by_mismatches.argtypes = [ctypes.c_double, ctypes.c_long, ctypes.c_ulonglong]
     from cfd_amd import cases
@@ -186,5 +188,10 @@ def test_div_by_constant_is_correctly_rounded(hm):
         for ln in (dx, dy, dz):
             hs.add((0.0 + ln / 2.0) + ln / 2.0)
             hs.add(2.0 * (((0.0 + ln / 3.0) + ln / 3.0) + ln / 3.0))
-    for i, h in enumerate(sorted(hs)):
+    for e in (-9, 0, 3):
+        hs.update([np.ldexp(1.0, e), np.nextafter(np.ldexp(1.0, e), 0.0), np.nextafter(np.ldexp(1.0, e), 4.0),
+                   np.ldexp(1.5, e), np.nextafter(np.ldexp(1.5, e), 0.0)])
+    rng = np.random.default_rng(77)
+    hs.update(np.ldexp(rng.uniform(1.0, 2.0, 24), rng.integers(-12, 4, 24)).tolist())
+    for i, h in enumerate(sorted(float(h) for h in hs)):
         assert hm.hm_div_by_mismatches(h, 2_000_000, 12345 + i) == 0, h
