@@ -120,9 +120,9 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from a separate rocprofv3 --pmc pass (scripts/record_traffic.py), if one
-    was recorded FOR THIS BUILD of the kernels: a record stamped with another source hash is not reported."""
+def counter_record(workload, kernel):
+    """The entry of profiles/traffic.json (separate rocprofv3 --pmc passes, scripts/record_traffic.py) for `kernel`,
+    if one was recorded FOR THIS BUILD of the kernels: a record stamped with another source hash is not reported."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -131,10 +131,28 @@ def measured_traffic(workload, kernel):
             return None
         for entry in rec.get(workload, []):
             if kernel.startswith(entry.get("kernel_prefix", "\0")):
-                return entry.get("hbm_bytes_per_launch")
+                return entry
         return None
     except (OSError, ValueError):
         return None
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the counter record, or None."""
+    entry = counter_record(workload, kernel)
+    return entry.get("hbm_bytes_per_launch") if entry else None
+
+
+def valu_issue(workload, kernel, launch_ms, sclk_mhz, n_simd=1024):
+    """How busy the launch keeps the fp64 vector pipes: issue slots the counters saw (4 cycles each, all SIMDs) over
+    the slots the launch's duration offers at the clock read while the steps ran.  None without a counter record."""
+    entry = counter_record(workload, kernel)
+    if not entry or not entry.get("valu_issue_slots_per_launch") or not sclk_mhz or not launch_ms:
+        return None
+    offered = n_simd * (launch_ms * 1e-3) * (sclk_mhz * 1e6) / 4.0
+    return {"wave_instructions_per_launch": entry.get("valu_wave_instructions_per_launch"),
+            "issue_slots_per_launch": entry["valu_issue_slots_per_launch"], "clock_mhz": sclk_mhz,
+            "frac_of_issue_slots": entry["valu_issue_slots_per_launch"] / offered}
 
 
 def spawn_ranks(a):
@@ -273,8 +291,30 @@ def main():
             def close(self):
                 self.m.close()
 
-        g = LibrarySlabs()
+        g, fallback = None, None
+        try:
+            g = LibrarySlabs()
+        except Exception as e:          # e.g. the library's RCCL communicator could not be created
+            if world == 1:
+                raise
+            fallback = "%s: %s" % (type(e).__name__, e)
+        if world > 1:
+            # every rank must take the same path: one failure sends all of them to the torch.distributed driver
+            ok = torch.tensor([0 if fallback else 1], dtype=torch.int64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()):
+                if g is not None:
+                    g.close()
+                    g = None
+                sys.stderr.write("rank %d: library slab driver unavailable (%s); using cfd_amd.slab over "
+                                 "torch.distributed\n" % (rank, fallback or "another rank failed"))
+                fallback = fallback or "another rank could not create its slab"
+                dist.destroy_process_group()
+                init_rccl(torch.device("cuda", local_rank))
+                c_driver, red_dev = False, "cuda"
     else:
+        fallback = None
+    if g is None:
         g = SlabGraph(params, fields, active, rank=rank, world=world)
 
     def barrier():
@@ -418,6 +458,8 @@ def main():
                      "cell_updates_per_cell_per_launch": dominant["cell_updates_per_cell"],
                      "avg_launch_ms": dominant["avg_pass_ms"], "launches": dominant["launches"],
                      "kernels": kinds,
+                     # the other limit of the same launch: fp64 vector issue slots in use (counter record of this build)
+                     "valu": valu_issue(workload, dominant["kernel"], dominant["avg_pass_ms"], sclk[0]),
                      # all sweep-type launches of a step together, cell-update bytes only
                      "step": {"sweep_kernel_ms": sweep_ms_per_step,
                               "achieved": SWEEPS_PER_STEP * cells_per_gpu * bytes_per_update / (sweep_ms_per_step / 1e3) / 1e9,
@@ -428,6 +470,8 @@ def main():
         out["roofline"]["note"] = ("slab run: a plain sweep is three launches (interior planes on the main stream, the "
                                    "planes next to the neighbours on a side stream beside it, where they share the GPU "
                                    "with the interior launch and the RCCL transfers); their durations are summed per sweep")
+    if fallback:
+        out["config"]["driver_fallback"] = fallback
     if strict is not None:
         out["strict"] = strict
     if rank == 0:

@@ -30,11 +30,11 @@ import numpy as np
 from .solver import AdjGraph
 
 
-def init_rccl(device, high_priority=True, **kw):
+def init_rccl(device, high_priority=False, **kw):
     """Process group on the nccl (= RCCL) backend bound to `device` (a torch.device).  high_priority: the
-    group's transfers run on a stream of torch's high-priority pool.  Streams of the normal pool can share a
-    hardware queue with the default stream, on which the sweeps run; an exchange queued behind a sweep in
-    the same hardware queue cannot run beside it, whatever the stream order allows."""
+    group's transfers run on a stream of torch's high-priority pool.  Off by default: on this runtime a step
+    that mixes stream priorities has been seen to stall once hardware queues have been handed on between
+    streams, and this driver does not overlap its exchanges with the sweeps anyway."""
     import torch.distributed as dist
     opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=bool(high_priority))
     dist.init_process_group("nccl", device_id=device, pg_options=opts, **kw)

@@ -1,5 +1,5 @@
 """Writes profiles/traffic.json from the counter summary of scripts/pmc.sh (separate rocprofv3 --pmc passes):
-HBM bytes per launch of the 2-D sweep kernels = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests as 64 B;
+vector-ALU instruction counts, and HBM bytes per launch of the 2-D sweep kernels = 2 x FETCH_SIZE (gfx950 tallies 128-B read requests as 64 B;
 checked in the same passes on time_filter_kernel, whose byte counts are known) + WRITE_SIZE, both in KB.
 The record is stamped with the SHA-256 of the kernel sources; bench.py reports it only for that build.
 usage: python scripts/record_traffic.py gpurun_out/<tag>/pmc2d_summary.txt [profiles/<round>/<copy>.txt]"""
@@ -30,7 +30,12 @@ for prefix, alg in (("sweep2d_stream", 81 * cells), ("sweep2d_pair", 2 * 81 * ce
                 "kernel_prefix": prefix, "kernel": k, "FETCH_SIZE_KB_raw": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
                 "hbm_bytes_per_launch": int(2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024),
                 "algorithmic_bytes_per_launch": alg,
-                "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B)"})
+                "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B)",
+                # vector-ALU side of the same launches (another pass of the same script): wave-level instructions and
+                # the 4-cycle issue slots they occupied, summed over all SIMDs
+                "valu_wave_instructions_per_launch": v.get("SQ_INSTS_VALU"),
+                "valu_issue_slots_per_launch": v.get("SQ_ACTIVE_INST_VALU"),
+                "wave_slots_per_launch": v.get("SQ_WAVE_CYCLES"), "waves_per_launch": v.get("SQ_WAVES")})
             break
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
