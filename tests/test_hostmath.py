@@ -195,3 +195,13 @@ def test_div_by_constant_is_correctly_rounded(hm):
     hs.update(np.ldexp(rng.uniform(1.0, 2.0, 24), rng.integers(-12, 4, 24)).tolist())
     for i, h in enumerate(sorted(float(h) for h in hs)):
         assert hm.hm_div_by_mismatches(h, 2_000_000, 12345 + i) == 0, h
+
+
+def test_host_arithmetic_under_sanitizers():
+    """Every host entry point of the harness on small ragged grids (1x1 up to 17x4, 7x2x6), built with
+    AddressSanitizer and UndefinedBehaviorSanitizer: `make -C tests/hostmath sanitize` must build and exit 0."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(HERE, "hostmath"), "-B", "sanitize"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "sanitize: ok" in r.stdout
