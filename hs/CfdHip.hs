@@ -63,6 +63,20 @@ foreign import ccall safe "cfd_total_density" c_density :: Ptr CfdHandle -> Ptr 
 foreign import ccall safe "cfd_read_fields" c_read :: Ptr CfdHandle -> CInt -> Ptr (Ptr Double) -> IO CInt
 foreign import ccall safe "cfd_time" c_time :: Ptr CfdHandle -> Ptr CInt -> Ptr CInt -> IO CInt
 foreign import ccall safe "cfd_last_error" c_last_error :: IO CString
+-- checkpoint / restart: a slot written back (slot_rel counted from the current currModTime), then the counters
+foreign import ccall safe "cfd_write_fields" c_write :: Ptr CfdHandle -> CInt -> Ptr (Ptr Double) -> IO CInt
+foreign import ccall safe "cfd_set_time" c_setTime :: Ptr CfdHandle -> CInt -> CInt -> IO CInt
+
+-- Several GPUs behind one handle: the whole grid goes in, the library cuts it into x-slabs (one per device, halo
+-- planes and the density sum over RCCL), and the solve loop calls the cfd_multi_* twins of the functions above.
+data CfdMulti
+foreign import ccall safe "cfd_multi_create"
+    c_multiCreate :: Ptr Params -> CInt -> Ptr CInt -> CInt -> Ptr (Ptr Double) -> Ptr Word8 -> Ptr (Ptr CfdMulti) -> IO CInt
+foreign import ccall safe "cfd_multi_destroy" c_multiDestroy :: Ptr CfdMulti -> IO ()
+foreign import ccall safe "cfd_multi_step" c_multiStep :: Ptr CfdMulti -> CInt -> IO CInt
+foreign import ccall safe "cfd_multi_total_density" c_multiDensity :: Ptr CfdMulti -> Ptr Double -> IO CInt
+foreign import ccall safe "cfd_multi_read_fields" c_multiRead :: Ptr CfdMulti -> CInt -> Ptr (Ptr Double) -> IO CInt
+foreign import ccall safe "cfd_multi_time" c_multiTime :: Ptr CfdMulti -> Ptr CInt -> Ptr CInt -> IO CInt
 
 check :: String -> CInt -> IO ()
 check what rc = when (rc /= 0) $ do
