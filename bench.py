@@ -313,7 +313,7 @@ def main():
                 init_rccl(torch.device("cuda", local_rank))
                 c_driver, red_dev = False, "cuda"
     else:
-        fallback = None
+        g, fallback = None, None
     if g is None:
         g = SlabGraph(params, fields, active, rank=rank, world=world)
 

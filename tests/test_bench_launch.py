@@ -33,3 +33,29 @@ def test_bench_gpus_2_without_a_gpu_fails_loudly():
     assert r.returncode != 0
     assert "needs a GPU" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [(), ("--virtual-slabs", "2"), ("--nz", "24", "--nx", "40", "--ny", "36")])
+def test_bench_line_on_the_gpu(extra):
+    """The command the round-end driver runs, shortened: ONE JSON line with the contract's keys, the roofline
+    and the finite-fields flag -- undecomposed, as two slabs behind the library's slab driver, and 3-D."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    args = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--warmup-seconds", "0", "--no-cpu-baseline"]
+    if "--nz" not in extra:
+        args += ["--nx", "256", "--ny", "512"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, *extra], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["dtype"] == "f64" and rec["value"] > 0
+    assert rec["config"]["fields_finite_at_end"] is True
+    assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
