@@ -1032,3 +1032,26 @@ def test_full_size_symmetry_3d(vary):
             sprof = sm[k].reshape(sdims)[tuple(first)].reshape(-1)
             assert bits_equal(prof, sprof), (vary, rel, PROPS[k])
         del big
+
+
+@pytest.mark.timeout(400)
+def test_strict_tiled_3d_matches_per_cell_at_256_cube():
+    """256 x 256 x 256 (19 x 19 tiles of 14 x 14 columns, 8 chunks of 32 planes), reference operation order: one
+    whole step of the tiled kernel (own products and left-hand sides through LDS, kept values refetched) against
+    the per-cell kernel, which shares none of that plumbing -- every slot bit-identical."""
+    from cfd_amd import cases
+    n = 256
+    params, fields, active = cases.synthetic_3d(n, n, n, seed=5)
+    params["dt"] = 1e-7
+    ga = _gpu_graph(params, fields, active, 0)
+    assert ga.kernel_name() == "sweep3d_march<strict>"
+    ga.step(1)
+    got = [ga.read_fields(rel) for rel in range(2)]
+    ga.close()
+    gb = _gpu_graph(params, fields, active, 1)
+    assert gb.kernel_name() == "sweep3d_simple<strict>"
+    gb.step(1)
+    for rel in range(2):
+        want = gb.read_fields(rel)
+        for k in range(7):
+            assert bits_equal(got[rel][k], want[k]), (rel, PROPS[k])
