@@ -2,7 +2,7 @@
 
 The hand-picked shapes of test_gpu_parity.py straddle the tile edges the author thought of; these draw the extents
 from every value next to a tile, wave or cache-line boundary of the launch shapes (2-D: 62/63/64, 126/128, 240/241,
-254/256, two tiles 480/496; 3-D: 12/14/16 and their multiples) and combine them with chunk lengths around 1, the
+254/256, two tiles 480/496; 3-D: 12/14/16 and their multiples) and combine them with chunk lengths of 1 to 7, the
 default 32 and primes, strict and re-associated arithmetic, with and without an identically zero V."""
 import numpy as np
 import pytest
