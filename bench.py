@@ -375,13 +375,13 @@ def main():
         g.close()
         params["flags"] = a.flags
         gs = SlabGraph(params, fields, active, rank=rank, world=world)
-        gs.step(1)
+        gs.step(3)
         barrier_s = lambda: (torch.cuda.synchronize(), gs.sync())
         barrier_s()
         gs.graph.set_timing(True)
         gs.graph.sweep_timing(reset=True)
         ts = time.perf_counter()
-        nstrict = max(2, min(5, a.steps))
+        nstrict = max(2, min(10, a.steps))
         gs.step(nstrict)
         barrier_s()
         es = time.perf_counter() - ts
