@@ -1,5 +1,5 @@
 """Interleaved timing of strict (reference operation order) sweep launch shapes in ONE process.
-usage: kstrict.py spec...   spec = variant:chunk ; env DIM = 2|3 (3), N = edge (256 in 3-D, 4096 in 2-D), ROUNDS (4)
+usage: kstrict.py spec...   spec = variant:chunk (chunk 'auto' = the library's choice); env DIM = 2|3 (3), N = edge (256 in 3-D, 4096 in 2-D), ROUNDS (4)
 Prints per spec the median / min time of the plain sweep and of the sweep fused with the filter (per sweep,
 all of its launches together)."""
 import os, sys, statistics
@@ -18,7 +18,9 @@ cells = n ** dim
 gs = []
 for spec in sys.argv[1:]:
     v, ch = spec.split(":")[:2]
-    os.environ["CFD_VARIANT"] = v; os.environ["CFD_CHUNK"] = ch
+    os.environ["CFD_VARIANT"] = v
+    if ch == "auto": os.environ.pop("CFD_CHUNK", None)     # the library's own choice
+    else: os.environ["CFD_CHUNK"] = ch
     g = AdjGraph(params, fields, active)
     g.step(2)
     g.set_timing(True); g.sweep_timing(); g.kernel_timing(1)
