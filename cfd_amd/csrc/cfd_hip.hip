@@ -477,6 +477,7 @@ __global__ void __launch_bounds__(NT, MINW)
 sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
                const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int ch,
                const double* __restrict__ fpp, double* __restrict__ fprev) {
+    constexpr bool ALWAYS = FILTER;         // finish every row, also the one before the chunk (see emit)
     __shared__ double lds[2][M::NSY][NT];
     __shared__ double lraw[2][NF2][NT];
     // OWN_FROM_LDS: a thread's private slot, two rows deep, for the left-hand sides and coefficients of the
@@ -510,7 +511,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     const long plane5 = (long)NF2 * ny;
     const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
     const unsigned vc = t <= nv + 1 ? (unsigned)cy * 8u : 0xFFFFFFF0u;     // lanes past the tile load nothing
-    const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
+    const unsigned vst_own = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;      // out of range: store dropped
     auto clampx = [=](int x) { return x < xlo ? xlo : (x > xhi ? xhi : x); };
     auto load_row = [&](int x, unsigned voff, double v[NF2]) {
         const PlaneRef p(src + (long)x * plane5, pbytes);
@@ -532,8 +533,16 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         }
     };
     // kept[]: OWN_FROM_LDS only -- the stored U, V, Dye of the row, fetched by row() for the inactive lanes
-    auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW,
+    // live: the row belongs to this block's chunk; otherwise (the row before the chunk) everything is computed and
+    // every store is dropped by its out-of-range offset.  With the filter, rows are finished unconditionally
+    // (ALWAYS): that keeps the compiler's vector-memory wait counts exact -- with the stores behind a branch it has
+    // to wait for ALL outstanding operations, the previous row's ten stores included, at the top of every row
+    // (-10 % on that launch).  Without the filter the branch stays: five stores drain fast enough, and the
+    // unconditional form measured 1 % slower.
+    auto emit = [&](int x, bool live, const typename M::PA& C, const typename M::SX& XE, const typename M::SX& XW,
                     const double pp[NF2], const double kept[3]) {
+        const unsigned vst = live ? vst_own : 0xFFFFFFF0u;
+        const int xr = live ? x : xs;           // a row the planes' descriptors can be built on
         typename M::SY YN, YS;
         M::get_sy(&lds[x & 1][0][lnc], NT, YN);
         M::get_sy(&lds[x & 1][0][lsc], NT, YS);
@@ -555,7 +564,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         auto own = [&](int i) { if constexpr (M::OWN_FROM_LDS) return kept[i]; else return M::own(C, i); };
         const double nU = select(am, o[E2_U], own(0)), nV = select(am, o[E2_V], own(1)),
                      nD = select(am, o[E2_DYE], own(2));
-        const PlaneRef d(dst + (long)x * plane5, pbytes);
+        const PlaneRef d(dst + (long)xr * plane5, pbytes);
         d.st_nt(vst, (unsigned)F2_RHO * fstride, o[E2_RHO]);
         d.st_nt(vst, (unsigned)F2_T * fstride, o[E2_T]);
         d.st_nt(vst, (unsigned)F2_U * fstride, nU);
@@ -563,7 +572,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         d.st_nt(vst, (unsigned)F2_DYE * fstride, nD);
         if (FILTER) {
             // Density and Temperature in every cell; U, V, Dye only where the cell is active
-            const PlaneRef pv(fprev + (long)x * plane5, pbytes);
+            const PlaneRef pv(fprev + (long)xr * plane5, pbytes);
             const unsigned vm = act ? vst : 0xFFFFFFF0u;
             pv.st_nt(vst, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (o[E2_RHO] - pp[F2_RHO])));
             pv.st_nt(vst, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (o[E2_T] - pp[F2_T])));
@@ -589,7 +598,11 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         x_half_slopes2(Rc, Re, Rw, hx);
         // Rw is dead: fetch row j+2 into it; also this row's mask
         load_row(clampx(j + 2), vc, Rw);
-        if (!first && j - 1 >= xs) { load_pp(j - 1, pp); load_kept(j - 1, kept); }
+        if (!first && (ALWAYS || j - 1 >= xs)) {        // (first: a compile-time constant at every call)
+            const int xr = j - 1 >= xs ? j - 1 : xs;
+            load_pp(xr, pp);
+            load_kept(xr, kept);
+        }
         const unsigned char act_n = load_act(j);
 #pragma unroll
         for (int f = 0; f < NF2; ++f) lraw[(j + 1) & 1][f][t] = Re[f];
@@ -609,7 +622,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
             }
         }
         const int x = j - 1;
-        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, pp, kept);   // block-uniform
+        if (!first && (ALWAYS || x >= xs)) emit(x, x >= xs, Ac, An.sx, Aw.sx, pp, kept);
         __syncthreads();
         act_c = act_n;
     };
@@ -636,9 +649,9 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
         double pp[NF2], kept[3];
         load_pp(xe - 1, pp);
         load_kept(xe - 1, kept);
-        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx, pp, kept);
-        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, pp, kept);
-        else emit(xe - 1, P2, P2.sx, P1.sx, pp, kept);
+        if (last == 0) emit(xe - 1, true, P0, P0.sx, P2.sx, pp, kept);
+        else if (last == 1) emit(xe - 1, true, P1, P1.sx, P0.sx, pp, kept);
+        else emit(xe - 1, true, P2, P2.sx, P1.sx, pp, kept);
     }
 }
 
@@ -1246,7 +1259,9 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
             }
         }
         const int x = j - 1;
-        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, kept);       // block-uniform
+        // block-uniform branch.  (Finishing every row unconditionally, as sweep2d_march2 does with the filter, costs this
+        // kernel 12 %: it has no registers left for the different schedule.)
+        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, kept);
         __syncthreads();
 #pragma unroll
         for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = Re[f];
