@@ -1,0 +1,81 @@
+// Memory-pattern probe for the 3-D sweep: the marching kernel's loads and stores without any arithmetic.
+// Layout as in the library: slot[((x*NF + f)*ny + y)*nz + z], NF = 6.  A block of 256 threads owns TY x TZ columns
+// (lanes along z) and walks CH x-planes; per plane every lane loads NF values from src (and NF from a second
+// buffer when FILT) and stores NF values to dst (and NF to a second one when FILT).
+// TILED: the same with a tile-blocked layout, a tile's TY*TZ values of one field and plane contiguous.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef int v2i __attribute__((ext_vector_type(2)));
+constexpr int NF = 6;
+
+template <int TY, int TZ, bool FILT, bool TILED, bool RD, bool WR>
+__global__ void __launch_bounds__(256) probe(const double* src, const double* src2, double* dst, double* dst2, int nx, int ny, int nz, int ch) {
+    const int t = threadIdx.x;
+    const bool on = t < TY * TZ;
+    const int ry = t / TZ, rz = t % TZ;
+    const int y = (int)blockIdx.y * TY + ry, z = (int)blockIdx.x * TZ + rz;
+    const int xs = (int)blockIdx.z * ch, xe = xs + ch < nx ? xs + ch : nx;
+    const long plane = (long)ny * nz;
+    const unsigned pbytes = (unsigned)(NF * plane * 8), fstride = (unsigned)(plane * 8);
+    unsigned cell;
+    if (TILED) cell = ((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * (TY * TZ) + t;
+    else cell = (unsigned)y * nz + z;
+    const unsigned voff = (on && y < ny && z < nz) ? cell * 8u : 0xFFFFFFF0u;
+    double carry[NF] = {0, 0, 0, 0, 0, 0};
+    for (int x = xs; x < xe; ++x) {
+        const long po = (long)x * NF * plane;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src) + po, 0, pbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src2) + po, 0, pbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst + po, 0, pbytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rd2 = __builtin_amdgcn_make_buffer_rsrc(dst2 + po, 0, pbytes, 0x00020000);
+        double v[NF], w[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            v[f] = RD ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, f * fstride, 0)) : (double)x;
+            w[f] = (RD && FILT) ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, f * fstride, 0)) : 1.0;
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if (WR) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, carry[f]), rd, voff, f * fstride, 2);
+            if (WR && FILT) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, carry[f] + 1.0), rd2, voff, f * fstride, 2);
+            carry[f] = v[f] + w[f];     // stores lag the loads by a plane, as in the sweep
+        }
+    }
+    if (!WR && carry[0] + carry[3] == 12345.678) dst[0] = carry[1];
+}
+
+template <int TY, int TZ, bool FILT, bool TILED, bool RD, bool WR>
+static void run(const char* name, double* a, double* b, double* c, double* d, int n, int ch) {
+    dim3 grid((n + TZ - 1) / TZ, (n + TY - 1) / TY, (n + ch - 1) / ch), block(256);
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<TY, TZ, FILT, TILED, RD, WR>), grid, block, 0, 0, a, b, c, d, n, n, n, ch);
+    CHECK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<TY, TZ, FILT, TILED, RD, WR>), grid, block, 0, 0, a, b, c, d, n, n, n, ch);
+    CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); CHECK(hipGetLastError());
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const double bytes = (double)n * n * n * NF * 8 * ((RD ? 1 : 0) + (WR ? 1 : 0)) * (FILT ? 2 : 1);
+    printf("%-44s tile %2dx%2d chunk %3d : %7.3f ms  %.2f TB/s\n", name, TY, TZ, ch, ms, bytes / ms / 1e9);
+}
+
+int main() {
+    const int n = 512;
+    const size_t sz = (size_t)n * n * n * NF * 8;
+    double *a, *b, *c, *d;
+    CHECK(hipMalloc(&a, sz)); CHECK(hipMalloc(&b, sz)); CHECK(hipMalloc(&c, sz)); CHECK(hipMalloc(&d, sz));
+    CHECK(hipMemset(a, 0, sz)); CHECK(hipMemset(b, 0, sz));
+    run<12, 16, false, false, true, true>("plain sweep pattern (read 6, write 6)", a, b, c, d, n, 32);
+    run<12, 16, false, true, true, true>("  same, tile-blocked layout", a, b, c, d, n, 32);
+    run<12, 16, true, false, true, true>("fused pattern (read 12, write 12)", a, b, c, d, n, 32);
+    run<12, 16, true, true, true, true>("  same, tile-blocked layout", a, b, c, d, n, 32);
+    run<12, 16, false, false, true, false>("reads only (6)", a, b, c, d, n, 32);
+    run<12, 16, false, true, true, false>("  same, tile-blocked layout", a, b, c, d, n, 32);
+    run<12, 16, false, false, false, true>("writes only (6)", a, b, c, d, n, 32);
+    run<12, 16, false, true, false, true>("  same, tile-blocked layout", a, b, c, d, n, 32);
+    run<8, 32, true, false, true, true>("fused pattern, 8 x 32 tile (256-byte runs)", a, b, c, d, n, 32);
+    run<4, 64, true, false, true, true>("fused pattern, 4 x 64 tile (512-byte runs)", a, b, c, d, n, 32);
+    run<12, 16, true, false, true, true>("fused pattern, chunk 64", a, b, c, d, n, 64);
+    return 0;
+}
