@@ -10,7 +10,7 @@
 typedef int v2i __attribute__((ext_vector_type(2)));
 constexpr int NF = 6;
 
-template <int TY, int TZ, bool FILT, bool TILED, bool RD, bool WR>
+template <int TY, int TZ, bool FILT, bool TILED, bool RD, bool WR, int LAUX = 0, int L2AUX = 0, int SAUX = 2>
 __global__ void __launch_bounds__(256) probe(const double* src, const double* src2, double* dst, double* dst2, int nx, int ny, int nz, int ch) {
     const int t = threadIdx.x;
     const bool on = t < TY * TZ;
@@ -33,27 +33,27 @@ __global__ void __launch_bounds__(256) probe(const double* src, const double* sr
         double v[NF], w[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            v[f] = RD ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, f * fstride, 0)) : (double)x;
-            w[f] = (RD && FILT) ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, f * fstride, 0)) : 1.0;
+            v[f] = RD ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, f * fstride, LAUX)) : (double)x;
+            w[f] = (RD && FILT) ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, f * fstride, L2AUX)) : 1.0;
         }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            if (WR) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, carry[f]), rd, voff, f * fstride, 2);
-            if (WR && FILT) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, carry[f] + 1.0), rd2, voff, f * fstride, 2);
+            if (WR) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, carry[f]), rd, voff, f * fstride, SAUX);
+            if (WR && FILT) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, carry[f] + 1.0), rd2, voff, f * fstride, SAUX);
             carry[f] = v[f] + w[f];     // stores lag the loads by a plane, as in the sweep
         }
     }
     if (!WR && carry[0] + carry[3] == 12345.678) dst[0] = carry[1];
 }
 
-template <int TY, int TZ, bool FILT, bool TILED, bool RD, bool WR>
+template <int TY, int TZ, bool FILT, bool TILED, bool RD, bool WR, int LAUX = 0, int L2AUX = 0, int SAUX = 2>
 static void run(const char* name, double* a, double* b, double* c, double* d, int n, int ch) {
     dim3 grid((n + TZ - 1) / TZ, (n + TY - 1) / TY, (n + ch - 1) / ch), block(256);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<TY, TZ, FILT, TILED, RD, WR>), grid, block, 0, 0, a, b, c, d, n, n, n, ch);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe<TY, TZ, FILT, TILED, RD, WR, LAUX, L2AUX, SAUX>), grid, block, 0, 0, a, b, c, d, n, n, n, ch);
     CHECK(hipEventRecord(e0));
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<TY, TZ, FILT, TILED, RD, WR>), grid, block, 0, 0, a, b, c, d, n, n, n, ch);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<TY, TZ, FILT, TILED, RD, WR, LAUX, L2AUX, SAUX>), grid, block, 0, 0, a, b, c, d, n, n, n, ch);
     CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); CHECK(hipGetLastError());
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const double bytes = (double)n * n * n * NF * 8 * ((RD ? 1 : 0) + (WR ? 1 : 0)) * (FILT ? 2 : 1);
@@ -77,5 +77,12 @@ int main() {
     run<8, 32, true, false, true, true>("fused pattern, 8 x 32 tile (256-byte runs)", a, b, c, d, n, 32);
     run<4, 64, true, false, true, true>("fused pattern, 4 x 64 tile (512-byte runs)", a, b, c, d, n, 32);
     run<12, 16, true, false, true, true>("fused pattern, chunk 64", a, b, c, d, n, 64);
+    run<12, 16, true, false, true, true, 0, 2, 2>("fused, older level loaded non-temporal", a, b, c, d, n, 32);
+    run<12, 16, true, false, true, true, 2, 2, 2>("fused, all loads non-temporal", a, b, c, d, n, 32);
+    run<12, 16, true, false, true, true, 0, 0, 0>("fused, plain stores", a, b, c, d, n, 32);
+    run<12, 16, true, false, true, true, 0, 1, 2>("fused, older level loaded glc", a, b, c, d, n, 32);
+    run<12, 16, true, false, true, true, 0, 0, 1>("fused, stores glc", a, b, c, d, n, 32);
+    run<12, 16, true, false, true, true, 0, 0, 3>("fused, stores glc+slc", a, b, c, d, n, 32);
+    run<12, 16, true, false, true, true>("fused pattern again", a, b, c, d, n, 32);
     return 0;
 }
