@@ -1141,10 +1141,12 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
 // threads have no neighbour on their outer side and use their own value there: what they publish
 // towards the patch does not depend on the slopes along that direction, and they store nothing.
 // LDS (dynamic): NF3 + NSY + NSZ doubles per thread (+ 4 * NE3 where the policy parks left-hand sides there).
-template <class M, int TY, int TZ, int MINW>
+// FILTER: the sweep that ends a step also applies the time filter to the values it has just computed.
+template <class M, int TY, int TZ, int MINW, bool FILTER = false>
 __global__ void __launch_bounds__(TY * TZ, MINW)
 sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
-              const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi, int ch) {
+              const uint8_t* __restrict__ active, int x0, int nx, int ny, int nz, int xlo, int xhi, int ch,
+              const double* __restrict__ fpp, double* __restrict__ fprev) {
     constexpr int NT = TY * TZ;
     constexpr int NSY = M::NSY;
     extern __shared__ double smem[];
@@ -1187,7 +1189,7 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
 
     // kept[]: OWN_FROM_LDS only -- the stored U, V, W, Dye of the row, fetched by row() for the inactive lanes
     auto emit = [&](int x, const typename M::PA& C, const typename M::SX& XP, const typename M::SX& XM,
-                    const double kept[4]) {
+                    const double kept[4], const double pp[NF3]) {
         typename M::SY YP, YM;
         typename M::SZ ZP, ZM;
         M::get_sy(lsy + lN, NT, YP);
@@ -1216,10 +1218,31 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         d.st(vst, (unsigned)F3_RHO * fstride, o[E3_RHO]);
         d.st(vst, (unsigned)F3_T * fstride, o[E3_T]);
         auto own = [&](int i) { if constexpr (M::OWN_FROM_LDS) return kept[i]; else return M::own(C, i); };
-        d.st(vst, (unsigned)F3_U * fstride, select(am, o[E3_U], own(0)));
-        d.st(vst, (unsigned)F3_V * fstride, select(am, o[E3_V], own(1)));
-        d.st(vst, (unsigned)F3_W * fstride, select(am, o[E3_W], own(2)));
-        d.st(vst, (unsigned)F3_DYE * fstride, select(am, o[E3_DYE], own(3)));
+        const double nU = select(am, o[E3_U], own(0)), nV = select(am, o[E3_V], own(1)),
+                     nW = select(am, o[E3_W], own(2)), nD = select(am, o[E3_DYE], own(3));
+        d.st(vst, (unsigned)F3_U * fstride, nU);
+        d.st(vst, (unsigned)F3_V * fstride, nV);
+        d.st(vst, (unsigned)F3_W * fstride, nW);
+        d.st(vst, (unsigned)F3_DYE * fstride, nD);
+        if (FILTER) {
+            // Density and Temperature in every cell; U, V, W, Dye only where the cell is active
+            const PlaneRef pv(fprev + (long)x * plane6, pbytes);
+            const unsigned vm = act_c != 0 ? vst : 0xFFFFFFF0u;
+            pv.st(vst, (unsigned)F3_RHO * fstride, pp[F3_RHO] + (0.5 * (o[E3_RHO] - pp[F3_RHO])));
+            pv.st(vst, (unsigned)F3_T * fstride, pp[F3_T] + (0.5 * (o[E3_T] - pp[F3_T])));
+            pv.st(vm, (unsigned)F3_U * fstride, pp[F3_U] + (0.5 * (nU - pp[F3_U])));
+            pv.st(vm, (unsigned)F3_V * fstride, pp[F3_V] + (0.5 * (nV - pp[F3_V])));
+            pv.st(vm, (unsigned)F3_W * fstride, pp[F3_W] + (0.5 * (nW - pp[F3_W])));
+            pv.st(vm, (unsigned)F3_DYE * fstride, pp[F3_DYE] + (0.5 * (nD - pp[F3_DYE])));
+        }
+    };
+    // stored values of row x in slot t-2, for the fused filter (issued early, consumed in emit)
+    auto load_pp = [&](int x, double pp[NF3]) {
+        if (FILTER) {
+            const PlaneRef q(fpp + (long)x * plane6, pbytes);
+#pragma unroll
+            for (int f = 0; f < NF3; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
+        }
     };
     // stored U, V, W, Dye of row x for the lanes whose cell is inactive there (the others fetch nothing)
     auto load_kept = [&](int x, double kept[4]) {
@@ -1241,8 +1264,8 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         for (int f = 0; f < NF3; ++f) h[0][f] = half_slope(Re[f], Rc[f], Rw[f]);
         load_row(clampx(j + 2), Rw);        // Rw is dead: fetch row j+2 into it
         const unsigned char act_n = load_act(j);
-        double kept[4];
-        if (!first && j - 1 >= xs) load_kept(j - 1, kept);
+        double kept[4], pp[NF3];
+        if (!first && j - 1 >= xs) { load_kept(j - 1, kept); load_pp(j - 1, pp); }
 #pragma unroll
         for (int f = 0; f < NF3; ++f) {
             h[1][f] = half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS]);
@@ -1260,8 +1283,8 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         }
         const int x = j - 1;
         // block-uniform branch.  (Finishing every row unconditionally, as sweep2d_march2 does with the filter, costs this
-        // kernel 12 %: it has no registers left for the different schedule.)
-        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, kept);
+        // kernel 12 % without and 20 % with the filter: it has no registers left for the different schedule.)
+        if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, kept, pp);
         __syncthreads();
 #pragma unroll
         for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = Re[f];
@@ -1291,11 +1314,12 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     }
     // last owned row of the domain: its clamped East neighbour is the cell itself
     if (j1 < xe) {
-        double kept[4];
+        double kept[4], pp[NF3];
         load_kept(xe - 1, kept);
-        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx, kept);
-        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, kept);
-        else emit(xe - 1, P2, P2.sx, P1.sx, kept);
+        load_pp(xe - 1, pp);
+        if (last == 0) emit(xe - 1, P0, P0.sx, P2.sx, kept, pp);
+        else if (last == 1) emit(xe - 1, P1, P1.sx, P0.sx, kept, pp);
+        else emit(xe - 1, P2, P2.sx, P1.sx, kept, pp);
     }
 }
 
@@ -1851,7 +1875,23 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
         dim3 block(TY * TZ), grid((p.nz + TZ - 3) / (TZ - 2), (p.ny + TY - 3) / (TY - 2),          \
                                   (x1 - x0 + ch - 1) / ch);                                           \
         hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, KK, src, dst, act,     \
-                              x0, x1, p.ny, p.nz, xlo, xhi, ch);                                     \
+                              x0, x1, p.ny, p.nz, xlo, xhi, ch, (const double*)nullptr, (double*)nullptr); \
+    } while (0)
+    // the strict default shape, with the time filter fused in where asked for
+#define LAUNCH_MARCH3_STRICT()                                                                      \
+    do {                                                                                           \
+        auto kern = fpp ? sweep3d_march<MathStrict3, 16, 16, 1, true> : sweep3d_march<MathStrict3, 16, 16, 1, false>; \
+        const size_t lds = march3_lds_bytes<MathStrict3>(256);                                     \
+        static bool attr_set[2][64] = {};                                                          \
+        if (lds > 64 * 1024 && !attr_set[fpp ? 1 : 0][h->device & 63]) {                           \
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                \
+            attr_set[fpp ? 1 : 0][h->device & 63] = true;                                          \
+        }                                                                                          \
+        dim3 block(256), grid((p.nz + 13) / 14, (p.ny + 13) / 14, (x1 - x0 + ch - 1) / ch);        \
+        hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, ea, eb, 0, h->K, src, dst, act,   \
+                              x0, x1, p.ny, p.nz, xlo, xhi, ch, fpp, fprev);                        \
+        fused = fpp != nullptr;                                                                    \
     } while (0)
 #define LAUNCH_STREAM3(TYW, TZW, NT, MINW, RDV)                                                     \
     do {                                                                                           \
@@ -1894,10 +1934,12 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                                           dim3(64), 0, h->stream, ea, eb, 0, h->K, src, dst, act, x0, x1, p.ny, p.nz,
                                           xlo, xhi);
                     break;
-                default: LAUNCH_MARCH3(MathStrict3, h->K, 16, 16, 1); break;
+                case 2: LAUNCH_MARCH3(MathStrict3, h->K, 16, 16, 1); break;       // never fused with the filter
+                default: LAUNCH_MARCH3_STRICT(); break;
             }
         }
 #undef LAUNCH_MARCH3
+#undef LAUNCH_MARCH3_STRICT
 #undef LAUNCH_STREAM3
     }
     HIP_TRY(hipGetLastError());
