@@ -84,7 +84,8 @@ def test_single_sweep_vs_libm_pow_form():
         assert rel_err(fg[k], f0[k]) <= 1e-13, PROPS[k]
 
 
-@pytest.mark.parametrize("flags,shape", [(0, (70, 300, 1)), (4, (70, 300, 1)), (4, (37, 29, 35)), (0, (12, 9, 7))])
+@pytest.mark.parametrize("flags,shape", [(0, (70, 300, 1)), (4, (70, 300, 1)), (4, (37, 29, 35)), (0, (12, 9, 7)),
+                                         (0, (37, 29, 35))])
 def test_fused_filter_equals_separate_filter(flags, shape):
     """cfd_step (filter fused into the third sweep where the kernel supports it) against sweep, sweep,
     sweep, filter launched separately: bit-identical in all three slots, for both arithmetic forms,
