@@ -1150,10 +1150,14 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     constexpr int NT = TY * TZ;
     constexpr int NSY = M::NSY;
     extern __shared__ double smem[];
-    double* const lraw = smem;                      // [NF3][NT]
-    double* const lsy = smem + NF3 * NT;            // [NSY][NT]
-    double* const lsz = lsy + NSY * NT;             // [NSZ][NT]
-    double* const lown = lsz + M::NSZ * NT;         // [2][2 * NE3][NT], OWN_FROM_LDS only: see row()
+    // Row stride of the LDS arrays: one slot more than the block, so that two rows are never a multiple of 512 bytes
+    // apart and the compiler cannot pair their reads into ds_read2st64_b64, which moves half as many bytes per LDS
+    // cycle as two ds_read_b64 do.
+    constexpr int LS = NT + 1;
+    double* const lraw = smem;                      // [NF3][LS]
+    double* const lsy = smem + NF3 * LS;            // [NSY][LS]
+    double* const lsz = lsy + NSY * LS;             // [NSZ][LS]
+    double* const lown = lsz + M::NSZ * LS;         // [2][2 * NE3][LS], OWN_FROM_LDS only: see row()
     const int t = threadIdx.x, tz = t % TZ, ty = t / TZ;
     const int zbase = (int)blockIdx.x * (TZ - 2) - 1, ybase = (int)blockIdx.y * (TY - 2) - 1;
     const int y = ybase + ty, z = zbase + tz;
@@ -1192,22 +1196,22 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
                     const double kept[4], const double pp[NF3]) {
         typename M::SY YP, YM;
         typename M::SZ ZP, ZM;
-        M::get_sy(lsy + lN, NT, YP);
-        M::get_sy(lsy + lS, NT, YM);
-        M::get_sz(lsz + lT, NT, ZP);
-        M::get_sz(lsz + lB, NT, ZM);
+        M::get_sy(lsy + lN, LS, YP);
+        M::get_sy(lsy + lS, LS, YM);
+        M::get_sz(lsz + lT, LS, ZP);
+        M::get_sz(lsz + lB, LS, ZM);
         double o[NE3];
         if constexpr (M::OWN_FROM_LDS) {
             // the cell's own y / z products are still in LDS, and row() has parked its left-hand sides and
             // coefficients there: read them back instead of carrying them in registers for a row
             typename M::PA Cl = C;
-            M::get_sy(lsy + t, NT, Cl.sy);
-            M::get_sz(lsz + t, NT, Cl.sz);
-            const double* lp = lown + (size_t)(x & 1) * (2 * NE3 * NT) + t;
+            M::get_sy(lsy + t, LS, Cl.sy);
+            M::get_sz(lsz + t, LS, Cl.sz);
+            const double* lp = lown + (size_t)(x & 1) * (2 * NE3 * LS) + t;
 #pragma unroll
             for (int e = 0; e < NE3; ++e) {
-                Cl.lhs[e] = lp[e * NT];
-                Cl.aU[e] = lp[(NE3 + e) * NT];
+                Cl.lhs[e] = lp[e * LS];
+                Cl.aU[e] = lp[(NE3 + e) * LS];
             }
             M::phaseB(K, Cl, XP, XM, YP, YM, ZP, ZM, o);
         } else {
@@ -1268,17 +1272,17 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         if (!first && j - 1 >= xs) { load_kept(j - 1, kept); load_pp(j - 1, pp); }
 #pragma unroll
         for (int f = 0; f < NF3; ++f) {
-            h[1][f] = half_slope(lraw[f * NT + lN], Rc[f], lraw[f * NT + lS]);
-            h[2][f] = half_slope(lraw[f * NT + lT], Rc[f], lraw[f * NT + lB]);
+            h[1][f] = half_slope(lraw[f * LS + lN], Rc[f], lraw[f * LS + lS]);
+            h[2][f] = half_slope(lraw[f * LS + lT], Rc[f], lraw[f * LS + lB]);
         }
         M::phaseA(K, Rc, h, An);
         if constexpr (M::OWN_FROM_LDS) {
             // this thread's own slot, two rows deep: no other thread reads it, so no barrier is involved
-            double* lp = lown + (size_t)(j & 1) * (2 * NE3 * NT) + t;
+            double* lp = lown + (size_t)(j & 1) * (2 * NE3 * LS) + t;
 #pragma unroll
             for (int e = 0; e < NE3; ++e) {
-                lp[e * NT] = An.lhs[e];
-                lp[(NE3 + e) * NT] = An.aU[e];
+                lp[e * LS] = An.lhs[e];
+                lp[(NE3 + e) * LS] = An.aU[e];
             }
         }
         const int x = j - 1;
@@ -1287,9 +1291,9 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
         if (!first && x >= xs) emit(x, Ac, An.sx, Aw.sx, kept, pp);
         __syncthreads();
 #pragma unroll
-        for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = Re[f];
-        M::put_sy(lsy + t, NT, An.sy);
-        M::put_sz(lsz + t, NT, An.sz);
+        for (int f = 0; f < NF3; ++f) lraw[f * LS + t] = Re[f];
+        M::put_sy(lsy + t, LS, An.sy);
+        M::put_sz(lsz + t, LS, An.sz);
         __syncthreads();
         act_c = act_n;
     };
@@ -1298,7 +1302,7 @@ sweep3d_march(typename M::Consts K, const double* __restrict__ src, double* __re
     load_row(j0, R1);
     load_row(clampx(j0 + 1), R2);
 #pragma unroll
-    for (int f = 0; f < NF3; ++f) lraw[f * NT + t] = R1[f];
+    for (int f = 0; f < NF3; ++f) lraw[f * LS + t] = R1[f];
     __syncthreads();
 
     row(j0, R0, R1, R2, P0, P0, P0, true);
@@ -1715,7 +1719,7 @@ static int scratch_setup(int device) {
 // support it; *did_fuse tells the caller whether it happened).
 template <class M>
 static size_t march3_lds_bytes(int nt) {
-    return (size_t)(NF3 + M::NSY + M::NSZ + (M::OWN_FROM_LDS ? 4 * NE3 : 0)) * nt * sizeof(double);
+    return (size_t)(NF3 + M::NSY + M::NSZ + (M::OWN_FROM_LDS ? 4 * NE3 : 0)) * (nt + 1) * sizeof(double);
 }
 
 // x0, x1: the range of owned x-planes to compute (x1 < 0: all of them).
