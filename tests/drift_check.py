@@ -1,5 +1,6 @@
 """Long-horizon check on one GPU: N steps of a 256 x 256 perturbed grid (the bench recipe, dt = 1e-7)
-with the strict kernel, the fast kernel and the CPU oracle in lock-step.  Reports, every `every`
+with the strict kernel, the fast kernel and the CPU oracle in lock-step (EDGE = edge of the 2-D grid;
+SHAPE3 = "nx,ny,nz" runs the 3-D recipe instead).  Reports, every `every`
 steps, the largest field difference strict-vs-oracle (expected: exactly 0), fast-vs-strict and, as
 a yardstick for how the scheme itself amplifies a last-bit difference, the oracle with libm pow
 against the oracle with T*sqrt(T) (all relative to the field scale), and the total-density
@@ -16,7 +17,11 @@ from oracle import OracleB
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 every = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 edge = int(os.environ.get("EDGE", 256))
-params, fields, active = cases.synthetic_2d(edge, edge, seed=4)
+shape3 = tuple(int(v) for v in os.environ["SHAPE3"].split(",")) if os.environ.get("SHAPE3") else None
+if shape3:
+    params, fields, active = cases.synthetic_3d(*shape3, seed=4)
+else:
+    params, fields, active = cases.synthetic_2d(edge, edge, seed=4)
 params["dt"] = 1e-7
 ps, pf = dict(params, flags=0), dict(params, flags=4)
 gs, gf = AdjGraph(ps, fields, active), AdjGraph(pf, fields, active)
@@ -37,7 +42,8 @@ for s in range(0, nsteps, every):
            "total_density_fast": gf.total_density(), "finite": bool(np.all(np.isfinite(ff[0])))}
     rows.append(row)
     print(json.dumps(row), flush=True)
-doc = {"grid": "%dx%dx1" % (edge, edge), "recipe": "cases.synthetic_2d seed 4, dt 1e-7", "steps": nsteps,
+doc = {"grid": "%dx%dx%d" % shape3 if shape3 else "%dx%dx1" % (edge, edge),
+       "recipe": "cases.synthetic_%s seed 4, dt 1e-7" % ("3d" if shape3 else "2d"), "steps": nsteps,
        "sweeps": 3 * nsteps, "seconds": time.time() - t0, "history": rows}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(doc, open(os.path.join(ROOT, "gpurun_out", "drift.json"), "w"), indent=1)
