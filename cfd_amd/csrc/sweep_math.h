@@ -111,7 +111,7 @@ CFD_HD long long to_bits(double x) {
 // A zero result may carry a sign bit; it is only ever added to / subtracted from the cell value,
 // where +0 and -0 act alike.  (For NaN inputs the reference's getSign calls NaN negative; NaN
 // fields are outside what this code reproduces.)
-CFD_HD double half_superbee(double a, double b) {
+CFD_HD double half_superbee_plain(double a, double b) {
     const long long sign = to_bits(a) & (long long)0x8000000000000000ull;
     const double sb = from_bits(to_bits(b) ^ sign);
     const double aa = fabs(a);
@@ -119,11 +119,35 @@ CFD_HD double half_superbee(double a, double b) {
     return from_bits(to_bits(m) | sign);
 }
 
+// The same value with the four maxima / minima written as single instructions.  Given fmax / fmin the compiler
+// first quiets a possible signalling NaN in sb (which comes out of an integer operation) with a v_max_f64 sb, sb
+// of its own: one instruction in nine.  NaN fields are outside what this code reproduces, and for every other
+// input the two forms return the same bits.  Kernels that run at the register limit keep the plain form
+// (an asm statement cannot be rematerialised or reordered into its users as freely).
+CFD_HD double half_superbee(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const long long sign = to_bits(a) & (long long)0x8000000000000000ull;
+    const double sb = from_bits(to_bits(b) ^ sign);
+    double hi, lo, m;
+    asm("v_max_f64 %0, |%1|, %2" : "=v"(hi) : "v"(a), "v"(sb));
+    asm("v_min_f64 %0, |%1|, %2" : "=v"(lo) : "v"(a), "v"(sb));
+    hi *= 0.5;
+    asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(hi), "v"(lo));
+    asm("v_max_f64 %0, %1, 0" : "=v"(m) : "v"(m));
+    return from_bits(to_bits(m) | sign);
+#else
+    return half_superbee_plain(a, b);
+#endif
+}
+
 CFD_HD double superbee(double a, double b) { return 2.0 * half_superbee(a, b); }
 
 // 0.5 * superbee(up - vc, vc - lo): the half-slope added to / subtracted from vc.
 CFD_HD double half_slope(double up, double vc, double lo) {
     return half_superbee(up - vc, vc - lo);
+}
+CFD_HD double half_slope_plain(double up, double vc, double lo) {
+    return half_superbee_plain(up - vc, vc - lo);
 }
 
 // x / h, correctly rounded, for a divisor h that is known in advance, with rh = RN(1/h) and rl = RN(1/h - rh).
@@ -218,12 +242,14 @@ struct SelMask {
     CFD_HD static mask of(bool c) { return mask_of(c); }
     CFD_HD static double pick(mask m, double x, double y) { return select(m, x, y); }
     CFD_HD static unsigned pick32(mask m, unsigned x, unsigned y) { return select_u32(m, x, y); }
+    CFD_HD static double half_slope(double up, double vc, double lo) { return cfd::half_slope(up, vc, lo); }
 };
 struct SelPlain {
     typedef bool mask;
     CFD_HD static mask of(bool c) { return c; }
     CFD_HD static double pick(mask m, double x, double y) { return m ? x : y; }
     CFD_HD static unsigned pick32(mask m, unsigned x, unsigned y) { return m ? x : y; }
+    CFD_HD static double half_slope(double up, double vc, double lo) { return half_slope_plain(up, vc, lo); }
 };
 
 // F * (1/phi), with the reference's NaN -> 1 substitution.
@@ -292,8 +318,9 @@ struct PhaseA2 {
 
 // x half-slopes of the five stored values: 0.5*superbee(e - c, c - w).  Split out of phase A so that
 // a kernel can retire the West row's registers (and reuse them for the next load) early.
+template <class S = SelMask>
 CFD_HD void x_half_slopes2(const double c[NF2], const double e[NF2], const double w[NF2], double hx[NF2]) {
-    for (int q = 0; q < NF2; ++q) hx[q] = half_slope(e[q], c[q], w[q]);
+    for (int q = 0; q < NF2; ++q) hx[q] = S::half_slope(e[q], c[q], w[q]);
 }
 
 // c,n,s: the five stored values (F2_* order) of the cell and of its clamped North/South neighbours;
@@ -739,7 +766,7 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     const double dea = visc_of(X, c[F2_U], hx[F2_U]), deb = visc_of(X, c[F2_V], hx[F2_V]);
     // ---- y faces
     double hy[NF2];
-    for (int q = 0; q < NF2; ++q) hy[q] = half_slope(n[q], c[q], s[q]);
+    for (int q = 0; q < NF2; ++q) hy[q] = S::half_slope(n[q], c[q], s[q]);
     const FluxDir Y = flux_dir(k, rho, hy[F2_RHO], T, hy[F2_T], c[F2_V], hy[F2_V]);
     div[E2_RHO] = fma(k.rcy2, Y.B, div[E2_RHO]);
     div[E2_U] = fma(k.rcy2, flux_of(Y, c[F2_U], hy[F2_U]), div[E2_U]);
