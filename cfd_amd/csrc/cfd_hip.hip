@@ -976,7 +976,7 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     auto iter = [&](int j, double* Rw, const double* Rc, const double* Re, double* Vw, double* Vc, double* Ve) {
         // ---- stage 1: phase A of row j, then finish row j-1
         double hx[NF2];
-        x_half_slopes2<SelPlain>(Rc, Re, Rw, hx);
+        x_half_slopes2<true>(Rc, Re, Rw, hx);
         load_row(clampx(j + 2), Rw);                        // Rw is dead: row j+2 goes into it
         const unsigned char act1 = load_act(clampx(j)), act2 = load_act(clampx(j - 2));
         double pp[NF2];
@@ -1016,7 +1016,7 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
         }
         // ---- stage 2: phase A of row j-2 on the once-swept values, then finish row j-3
         double hx2[NF2], rn2[NF2], rs2[NF2];
-        x_half_slopes2<SelPlain>(Vc, Ve, Vw, hx2);
+        x_half_slopes2<true>(Vc, Ve, Vw, hx2);
 #pragma unroll
         for (int f = 0; f < NF2; ++f) { rn2[f] = lraw2[f][lnc]; rs2[f] = lraw2[f][lsc]; }
         StreamA2 B;
@@ -1069,7 +1069,7 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     // starting rotation.  Same LDS protocol and barriers as iter.
     auto iter_stage1 = [&](int j, double* Rw, const double* Rc, const double* Re, double* Vw, double* Vc, double* Ve) {
         double hx[NF2];
-        x_half_slopes2<SelPlain>(Rc, Re, Rw, hx);
+        x_half_slopes2<true>(Rc, Re, Rw, hx);
         load_row(clampx(j + 2), Rw);
         const unsigned char act1 = load_act(clampx(j));
         double rn[NF2], rs[NF2];

@@ -122,8 +122,8 @@ CFD_HD double half_superbee_plain(double a, double b) {
 // The same value with the four maxima / minima written as single instructions.  Given fmax / fmin the compiler
 // first quiets a possible signalling NaN in sb (which comes out of an integer operation) with a v_max_f64 sb, sb
 // of its own: one instruction in nine.  NaN fields are outside what this code reproduces, and for every other
-// input the two forms return the same bits.  Kernels that run at the register limit keep the plain form
-// (an asm statement cannot be rematerialised or reordered into its users as freely).
+// input the two forms return the same bits.  Where a kernel at the register limit spills with this form it keeps
+// the plain one (x_half_slopes2<true>).
 CFD_HD double half_superbee(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const long long sign = to_bits(a) & (long long)0x8000000000000000ull;
@@ -242,14 +242,12 @@ struct SelMask {
     CFD_HD static mask of(bool c) { return mask_of(c); }
     CFD_HD static double pick(mask m, double x, double y) { return select(m, x, y); }
     CFD_HD static unsigned pick32(mask m, unsigned x, unsigned y) { return select_u32(m, x, y); }
-    CFD_HD static double half_slope(double up, double vc, double lo) { return cfd::half_slope(up, vc, lo); }
 };
 struct SelPlain {
     typedef bool mask;
     CFD_HD static mask of(bool c) { return c; }
     CFD_HD static double pick(mask m, double x, double y) { return m ? x : y; }
     CFD_HD static unsigned pick32(mask m, unsigned x, unsigned y) { return m ? x : y; }
-    CFD_HD static double half_slope(double up, double vc, double lo) { return half_slope_plain(up, vc, lo); }
 };
 
 // F * (1/phi), with the reference's NaN -> 1 substitution.
@@ -318,9 +316,11 @@ struct PhaseA2 {
 
 // x half-slopes of the five stored values: 0.5*superbee(e - c, c - w).  Split out of phase A so that
 // a kernel can retire the West row's registers (and reuse them for the next load) early.
-template <class S = SelMask>
+// PLAIN: the limiter's portable form (the two-sweeps kernel, which runs close to the register limit, spills with
+// the single-instruction form here; its y slopes take that form without harm).
+template <bool PLAIN = false>
 CFD_HD void x_half_slopes2(const double c[NF2], const double e[NF2], const double w[NF2], double hx[NF2]) {
-    for (int q = 0; q < NF2; ++q) hx[q] = S::half_slope(e[q], c[q], w[q]);
+    for (int q = 0; q < NF2; ++q) hx[q] = PLAIN ? half_slope_plain(e[q], c[q], w[q]) : half_slope(e[q], c[q], w[q]);
 }
 
 // c,n,s: the five stored values (F2_* order) of the cell and of its clamped North/South neighbours;
@@ -766,7 +766,7 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     const double dea = visc_of(X, c[F2_U], hx[F2_U]), deb = visc_of(X, c[F2_V], hx[F2_V]);
     // ---- y faces
     double hy[NF2];
-    for (int q = 0; q < NF2; ++q) hy[q] = S::half_slope(n[q], c[q], s[q]);
+    for (int q = 0; q < NF2; ++q) hy[q] = half_slope(n[q], c[q], s[q]);
     const FluxDir Y = flux_dir(k, rho, hy[F2_RHO], T, hy[F2_T], c[F2_V], hy[F2_V]);
     div[E2_RHO] = fma(k.rcy2, Y.B, div[E2_RHO]);
     div[E2_U] = fma(k.rcy2, flux_of(Y, c[F2_U], hy[F2_U]), div[E2_U]);
