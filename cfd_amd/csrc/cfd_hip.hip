@@ -27,6 +27,9 @@
 
 using namespace cfd;
 
+// CFD_KERNEL_TEMPLATES_ONLY: a second translation unit (cfd_strict2d_lean.hip) includes this file for the kernel
+// templates alone and instantiates one of them under other compiler options.
+#ifndef CFD_KERNEL_TEMPLATES_ONLY
 static constexpr int GHOST = 2;      // ghost x-planes allocated on either side of the owned planes
 
 // ------------------------------------------------------------------------------------------
@@ -109,6 +112,8 @@ static inline double* slot_base(const cfd_handle* h, int t) {
     // points at plane x = 0, field 0
     return h->buf[h->map[t]] + (size_t)GHOST * h->nf * h->plane;
 }
+
+#endif  // CFD_KERNEL_TEMPLATES_ONLY
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -472,17 +477,20 @@ struct PlaneRef {
 //                 phase B of row j-1 (centre = row j-1, East = row j, West = row j-2,
 //                                     North/South = lds[(j-1)&1] of the neighbouring lanes)
 //                 one barrier
-template <class M, int NT, int MINW, bool FILTER, int WCOLS = NT - 2>
+//   LEAN (strict arithmetic, no filter): 39 instead of 54 doubles of LDS per thread, so that four 128-thread blocks
+//   fit a compute unit (two waves per SIMD): the neighbours' stored values are single-buffered behind a second
+//   barrier per row, and only the left-hand sides are parked in LDS (the coefficients stay in registers).
+template <class M, int NT, int MINW, bool FILTER, int WCOLS = NT - 2, bool LEAN = false>
 __global__ void __launch_bounds__(NT, MINW)
 sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __restrict__ dst,
                const uint8_t* __restrict__ active, int x0, int nx, int ny, int xlo, int xhi, int ch,
                const double* __restrict__ fpp, double* __restrict__ fprev) {
     constexpr bool ALWAYS = FILTER;         // finish every row, also the one before the chunk (see emit)
     __shared__ double lds[2][M::NSY][NT];
-    __shared__ double lraw[2][NF2][NT];
+    __shared__ double lraw[LEAN ? 1 : 2][NF2][NT];
     // OWN_FROM_LDS: a thread's private slot, two rows deep, for the left-hand sides and coefficients of the
     // row it has evaluated but not yet finished (instead of carrying them in registers for a row)
-    __shared__ double lown[2][10][M::OWN_FROM_LDS ? NT : 1];
+    __shared__ double lown[2][LEAN ? 5 : 10][M::OWN_FROM_LDS ? NT : 1];
     const int t = threadIdx.x;
     // Lanes 0 .. WCOLS-1 hold the block's own columns in order (with WCOLS a multiple of 16 every
     // wave's store covers whole 128-byte lines), lane WCOLS the column above the tile, lane WCOLS+1
@@ -553,7 +561,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
 #pragma unroll
             for (int e = 0; e < 5; ++e) {
                 Cl.lhs[e] = lown[x & 1][e][t];
-                Cl.aU[e] = lown[x & 1][5 + e][t];
+                if constexpr (!LEAN) Cl.aU[e] = lown[x & 1][5 + e][t];
             }
             M::phaseB(K, Cl, XE, XW, YN, YS, o);
         } else {
@@ -604,13 +612,25 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
             load_kept(xr, kept);
         }
         const unsigned char act_n = load_act(j);
-#pragma unroll
-        for (int f = 0; f < NF2; ++f) lraw[(j + 1) & 1][f][t] = Re[f];
         double rn[NF2], rs[NF2];
+        if constexpr (LEAN) {
+            // one tile: every lane has read row j before any lane overwrites it with row j+1
 #pragma unroll
-        for (int f = 0; f < NF2; ++f) {
-            rn[f] = lraw[j & 1][f][lnc];
-            rs[f] = lraw[j & 1][f][lsc];
+            for (int f = 0; f < NF2; ++f) {
+                rn[f] = lraw[0][f][lnc];
+                rs[f] = lraw[0][f][lsc];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) lraw[0][f][t] = Re[f];
+        } else {
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) lraw[(j + 1) & 1][f][t] = Re[f];
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) {
+                rn[f] = lraw[j & 1][f][lnc];
+                rs[f] = lraw[j & 1][f][lsc];
+            }
         }
         M::phaseA(K, Rc, hx, rn, rs, An);
         M::put_sy(&lds[j & 1][0][t], NT, An.sy);
@@ -618,7 +638,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
 #pragma unroll
             for (int e = 0; e < 5; ++e) {
                 lown[j & 1][e][t] = An.lhs[e];
-                lown[j & 1][5 + e][t] = An.aU[e];
+                if constexpr (!LEAN) lown[j & 1][5 + e][t] = An.aU[e];
             }
         }
         const int x = j - 1;
@@ -631,7 +651,7 @@ sweep2d_march2(typename M::Consts K, const double* __restrict__ src, double* __r
     load_row(j0, vc, R1);
     load_row(clampx(j0 + 1), vc, R2);
 #pragma unroll
-    for (int f = 0; f < NF2; ++f) lraw[j0 & 1][f][t] = R1[f];
+    for (int f = 0; f < NF2; ++f) lraw[LEAN ? 0 : (j0 & 1)][f][t] = R1[f];
     __syncthreads();
 
     row(j0, R0, R1, R2, P0, P0, P0, true);
@@ -1569,6 +1589,7 @@ sweep3d_stream(FastConsts K, const double* __restrict__ src, double* __restrict_
     }
 }
 
+#ifndef CFD_KERNEL_TEMPLATES_ONLY
 // correctPrevTime: prev <- pp + 0.5*(c - pp); Density and Temperature in every cell, the
 // other fields only where the cell is active.  Grid: (ceil(plane/256), nf, nx).
 __global__ void __launch_bounds__(256)
@@ -1758,6 +1779,12 @@ static int march_chunk(int nplanes, long tiles, long slots) {
     return best;
 }
 
+// The strict 2-D sweep without the filter, LEAN form, instantiated in cfd_strict2d_lean.hip (compiled with the
+// minimum-register scheduling strategy, under which it fits 256 registers: two waves per SIMD).
+extern "C" int cfd_internal_launch_strict2d_lean(const SweepConsts* K, const double* src, double* dst,
+                                                 const uint8_t* act, int x0, int x1, int ny, int xlo, int xhi, int ch,
+                                                 void* stream, void* ev_begin, void* ev_end);
+
 static int launch_sweep(cfd_handle* h, const double* src, double* dst, const double* fpp = nullptr,
                         double* fprev = nullptr, bool* did_fuse = nullptr, int x0 = 0, int x1 = -1) {
     bool fused = false;
@@ -1791,9 +1818,10 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
             hipExtLaunchKernelGGL(sweep2d_simple<MathStrict2>, grid, block, 0, h->stream, ea, eb, 0, h->K, src, dst,
                                   act, x0, x1, p.ny, xlo, xhi);
     } else if (h->two_d) {
+        static const bool strict_lean = !getenv("CFD_STRICT_LEAN") || atoi(getenv("CFD_STRICT_LEAN")) != 0;
         const int ch = !(h->chunk_auto && h->variant < 0) ? h->chunk
                        : fast ? stream_chunk(h, x1 - x0)
-                              : march_chunk(x1 - x0, (p.ny + 125) / 126, 2L * h->cus);   // 128 threads, two blocks per CU
+                              : march_chunk(x1 - x0, (p.ny + 125) / 126, (fpp || !strict_lean ? 2L : 4L) * h->cus);   // 128 threads, two (LEAN: four) blocks per CU
 #define LAUNCH_MARCH2(M, KK, NT, MINW) LAUNCH_MARCH2W(M, KK, NT, MINW, (NT - 2))
 #define LAUNCH_MARCH2W(M, KK, NT, MINW, WC)                                                         \
     do {                                                                                           \
@@ -1846,7 +1874,15 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
                 case 12: LAUNCH_MARCH2(MathStrict2, h->K, 256, 1); break;
                 case 13: LAUNCH_MARCH2W(MathStrict2, h->K, 256, 1, 240); break;
                 case 14: LAUNCH_MARCH2W(MathStrict2, h->K, 128, 1, 112); break;
-                default: LAUNCH_MARCH2(MathStrict2, h->K, 128, 1); break;      // 8
+                default:        // 8
+                    if (!fpp && strict_lean && h->variant < 0) {
+                        HIP_TRY((hipError_t)cfd_internal_launch_strict2d_lean(&h->K, src, dst, act, x0, x1, p.ny, xlo, xhi,
+                                                                              ch, (void*)h->stream, (void*)ea, (void*)eb));
+                        fused = false;
+                    } else {
+                        LAUNCH_MARCH2(MathStrict2, h->K, 128, 1);
+                    }
+                    break;
             }
         }
 #undef LAUNCH_MARCH2
@@ -2583,3 +2619,4 @@ int cfd_live_fields(cfd_handle* h, int* nfields) {
 }
 
 }  // extern "C"
+#endif  // CFD_KERNEL_TEMPLATES_ONLY
