@@ -354,6 +354,7 @@ def main():
     kernel_ms, launches = g.graph.sweep_timing(reset=True)
     fused_ms, fused_launches = g.graph.kernel_timing(1, reset=True)
     pair_ms, pair_launches = g.graph.kernel_timing(2, reset=True)
+    trio_ms, trio_launches = g.graph.kernel_timing(3, reset=True)
     g.graph.set_timing(False)
     base_name = g.graph.kernel_name()
     if world > 1:
@@ -364,7 +365,7 @@ def main():
     if c_driver and a.virtual_slabs > 1:
         # launches were timed on the first of the K slabs only: scale to the whole GPU
         scale = a.virtual_slabs
-        kernel_ms, fused_ms, pair_ms = kernel_ms * scale, fused_ms * scale, pair_ms * scale
+        kernel_ms, fused_ms, pair_ms, trio_ms = kernel_ms * scale, fused_ms * scale, pair_ms * scale, trio_ms * scale
     cells_per_gpu = a.nx * a.ny * a.nz                   # this rank's cells (rank 0 reports)
     total_cells = global_nx * a.ny * a.nz
     final_density = g.total_density()
@@ -396,9 +397,10 @@ def main():
     updates = total_cells * SWEEPS_PER_STEP * a.steps
     bytes_per_update = BYTES_PER_UPDATE_2D if two_d else BYTES_PER_UPDATE_3D
     # Launch kinds in the timed region, per step: three plain sweeps; or two plus one fused with the filter; or one
-    # plain sweep plus one launch that does two sweeps and the filter in one pass.  At N > 1 a sweep is two or three
-    # launches (interior planes, then the planes next to a ghost plane); their times are summed per sweep.
-    plain_sweeps = (1 if pair_launches else (2 if fused_launches else 3)) * a.steps
+    # plain sweep plus one launch that does two sweeps and the filter in one pass; or ONE launch that does the whole
+    # step (three sweeps and the filter) in one pass.  At N > 1 a sweep is two or three launches (interior planes,
+    # then the planes next to a ghost plane); their times are summed per sweep.
+    plain_sweeps = (0 if trio_launches else 1 if pair_launches else (2 if fused_launches else 3)) * a.steps
 
     def kind_record(name, total_ms, nlaunch, passes, updates_per_cell, filters_per_cell):
         """Roofline figures of one launch kind.  Algorithmic bytes count the cell-update units only
@@ -414,7 +416,11 @@ def main():
         rec["frac"] = rec["achieved"] / HBM_PEAK_GBPS
         return rec
 
-    kinds = [kind_record(base_name, kernel_ms, launches, plain_sweeps, 1, 0)]
+    kinds = []
+    if plain_sweeps:
+        kinds.append(kind_record(base_name, kernel_ms, launches, plain_sweeps, 1, 0))
+    if trio_launches:
+        kinds.append(kind_record("sweep2d_trio (three sweeps + filter in one pass)", trio_ms, trio_launches, a.steps, 3, 1))
     if fused_launches:
         kinds.append(kind_record(base_name + " + filter", fused_ms, fused_launches, a.steps, 1, 1))
     if pair_launches:

@@ -57,8 +57,10 @@ extern "C" int cfd_internal_fail(int code, const char* msg) { return fail(code, 
 // ------------------------------------------------------------------------------------------
 struct EventPair {
     hipEvent_t a, b;
-    int kind;       // 0 = sweep, 1 = sweep fused with the time filter, 2 = two sweeps (+ filter) in one pass
+    int kind;       // 0 = sweep, 1 = sweep fused with the time filter, 2 = two sweeps (+ filter) in one pass,
+                    // 3 = a whole step (three sweeps + filter) in one pass
 };
+static constexpr int NKIND = 4;
 
 struct cfd_handle {
     cfd_params p;
@@ -86,6 +88,9 @@ struct cfd_handle {
     bool march3_ok;         // a 3-D x-plane fits 32-bit byte offsets (tiled 3-D kernel usable)
     bool pair_enabled;      // cfd_step runs its second and third sweep in one pass (env CFD_PAIR, default on)
     int pair_chunk;         // x-planes per block of that kernel (env CFD_PAIR_CHUNK)
+    bool trio_enabled;      // cfd_step runs all three sweeps of a step in one pass (env CFD_TRIO, default on)
+    int trio_chunk;         // x-planes per block of that kernel (env CFD_TRIO_CHUNK)
+    int trio_nts;           // its threads per sweep stage: 256 (one block per compute unit) or 128 (two)
     // a sweep split into cfd_sweep_begin / cfd_sweep_end
     struct {
         bool open, step_time, with_filter, fused;
@@ -98,8 +103,8 @@ struct cfd_handle {
     // sweep timing
     bool timing;
     std::vector<EventPair> ev_used, ev_free;
-    double t_ms[3];
-    int64_t t_launches[3];
+    double t_ms[NKIND];
+    int64_t t_launches[NKIND];
 };
 
 // field order inside a plane
@@ -1151,6 +1156,265 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     }
 }
 
+// A whole step in one pass over memory (re-associated arithmetic, streamed messages): dst = S(S(S(src))), the three
+// sweeps of runSingleStep, optionally followed by the time filter.  The two intermediate fields live only in LDS.
+// A step then moves 81 + 80 bytes per cell (source + mask + filter input read, new values + filtered values written)
+// instead of 81 + 161.
+//
+// One group of NTS threads per sweep ("stage"): stage 0 reads the stored values from memory, stage 1 works on the
+// once-swept values, stage 2 on the twice-swept values and stores.  Every stage runs the row loop of sweep2d_stream
+// on its own input, so a thread carries one sweep's state only (the register budget of the single sweep, three waves
+// per SIMD), and the block's 3 * NTS / 64 waves put one wave of every stage on each SIMD.  A stage hands a finished
+// row to the next one through a ring of three rows in LDS: written in iteration i, read by the consumer in
+// iterations i+1 (as the row East of its centre row; own column) and i+2 (as its centre row: the North / South
+// neighbours' values), overwritten in i+3.  One barrier per iteration, all stages in lock-step; iteration i has
+// stage s evaluate row xs - 3 + i - 3 s of its input and finish the row before it.
+//
+// Lanes of a stage group: the tile's own columns first, then the columns +1, -1, +2, -2, +3, -3 beside the tile
+// (stage 0 needs all six, stage 1 the first four, stage 2 the first two: the outermost pair of a stage only sends
+// messages and stored values inwards); further lanes idle.  Tiles: widths are multiples of 16 columns, as equal as
+// possible (trio_tiles), so every block runs all its waves and stores whole 128-byte lines.
+// Clamp-to-self at the ends of the domain applies to each sweep separately; a stage gets it, as sweep2d_stream
+// does, from clamped row indices into its input (the producer writes only rows on which its output is defined):
+//   stage s reads input rows lo_s .. hi_s,  lo_s = min(lo0 + s, 0),  hi_s = max(hi0 - s, nx - 1).
+#ifndef CFD_TRIO_PRIO
+#define CFD_TRIO_PRIO 1
+#endif
+static constexpr bool TRIO_PRIO = CFD_TRIO_PRIO != 0;
+struct TrioTiles { int ntile, lines; };
+__host__ __device__ inline TrioTiles trio_tiles(int ny, int wmax) {
+    const int lines = (ny + 15) / 16, per = wmax / 16;
+    return TrioTiles{(lines + per - 1) / per, lines};
+}
+__host__ __device__ inline int trio_tile_start(const TrioTiles& tp, int i) {
+    return (int)(((long)i * tp.lines) / tp.ntile) * 16;
+}
+
+// LDS of the three-sweeps kernel, in rows of NTS doubles: messages [3 stages][2][6], stored values of stage 0's
+// current and next row [2][NF2], rings of once- and twice-swept rows [3][NF2] each.
+static constexpr int TRIO_LDS_ROWS = 36 + 2 * NF2 + 2 * 3 * NF2;
+
+// Issue priority by progress through the row (see NoPhaseHook): 3 at the top of a row, down to 0 at its end.
+struct TrioPrioHook {
+    __device__ __forceinline__ static void at(int k) {
+        if (k == 1) __builtin_amdgcn_s_setprio(2);
+        else if (k == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+};
+
+template <int STAGE, int NTS, bool FILTER>
+__device__ __forceinline__ void trio_stage(const FastConsts& K, const double* __restrict__ src, double* __restrict__ dst,
+                                           const uint8_t* __restrict__ active, int nx, int ny, int lo0, int hi0, int xs,
+                                           int xe, int ytile, int nv, int tl, int wave0, const double* __restrict__ fpp,
+                                           double* __restrict__ fprev, double* __restrict__ smem) {
+    // waves without a used lane leave at once (a barrier counts only the waves that have not ended); unused lanes
+    // of the other waves are masked off for the rest of the kernel
+    constexpr int HALO = 6 - 2 * STAGE;
+    if (wave0 > nv + HALO - 1) return;
+    double (*const lmsg)[6][NTS] = reinterpret_cast<double (*)[6][NTS]>(smem + (size_t)STAGE * 12 * NTS);
+    double (*const raw0)[NF2][NTS] = reinterpret_cast<double (*)[NF2][NTS]>(smem + (size_t)36 * NTS);
+    double* const ring1 = smem + (size_t)(36 + 2 * NF2) * NTS;
+    double* const ring2 = ring1 + (size_t)3 * NF2 * NTS;
+    const double* const ring_in = STAGE == 1 ? ring1 : ring2;      // (stage 0 reads memory)
+    double* const ring_out = STAGE == 0 ? ring1 : ring2;           // (stage 2 stores to memory)
+    // what this stage publishes starts out defined, in the slots of its unused lanes too (an outermost column reads
+    // them as its outer neighbour's; nothing it hands inwards depends on them)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { lmsg[0][e][tl] = 0.0; lmsg[1][e][tl] = 0.0; }
+    if constexpr (STAGE < 2) {
+#pragma unroll
+        for (int u = 0; u < 3 * NF2; ++u) ring_out[(size_t)u * NTS + tl] = 1.0;
+    }
+    if (tl > nv + HALO - 1) return;
+    // lane -> column: own columns, then +1 above, -1 below, +2, -2, +3, -3
+    const int k = tl - nv;
+    const int y = k < 0 ? ytile + tl : ((k & 1) ? ytile - 1 - (k >> 1) : ytile + nv + (k >> 1));
+    const int cy = y < 0 ? 0 : (y > ny - 1 ? ny - 1 : y);
+    const int yn = cy + 1 > ny - 1 ? ny - 1 : cy + 1, ys = cy - 1 < 0 ? 0 : cy - 1;
+    auto lane_of = [=](int c) {         // lane that holds column c; beyond the tile's halo: this lane (own value)
+        const int r = c - ytile;
+        if (r >= 0 && r < nv) return r;
+        if (r >= nv && r < nv + 3) return nv + 2 * (r - nv);
+        if (r < 0 && r >= -3) return nv + 2 * (-r - 1) + 1;
+        return tl;
+    };
+    const int lnc = lane_of(yn), lsc = lane_of(ys);
+    const bool writer = tl < nv;
+    const long plane5 = (long)NF2 * ny;
+    const unsigned pbytes = (unsigned)(plane5 * 8), fstride = (unsigned)ny * 8u;
+    const unsigned vc = (unsigned)cy * 8u;
+    const unsigned vst = writer ? (unsigned)y * 8u : 0xFFFFFFF0u;       // out of range: store dropped
+    // rows this stage's input is defined on
+    const int lo = lo0 + STAGE > 0 ? 0 : lo0 + STAGE, hi = hi0 - STAGE < nx - 1 ? nx - 1 : hi0 - STAGE;
+    // rows that get a phase A: the first and the last one only send their East / West message
+    const int afirst = xs - 3 + STAGE > lo ? xs - 3 + STAGE : lo;
+    const int alast = xe + 2 - STAGE < hi + 1 ? xe + 2 - STAGE : hi + 1;
+    const int nit = xe - xs + 10;           // iterations of the block, the same for every stage
+    auto clampr = [=](int r) { return r < lo ? lo : (r > hi ? hi : r); };
+    auto slot3 = [](int r) { return (int)((unsigned)(r + 3072) % 3u); };
+    auto load_row = [&](int x, double v[NF2]) {
+        const PlaneRef p(src + (long)x * plane5, pbytes);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) v[f] = p.ld(vc, (unsigned)f * fstride);
+    };
+    auto ring_row = [&](int r, double v[NF2]) {
+        const double* p = ring_in + (size_t)slot3(clampr(r)) * (NF2 * NTS) + tl;
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) v[f] = p[f * NTS];
+    };
+    auto load_act = [&](int x) { return PlaneRef(active + (long)x * ny, (unsigned)ny).ldb((unsigned)cy); };
+
+    double R[3][NF2];
+    double pq[4] = {0, 0, 0, 0}, pcoef[4] = {0, 0, 0, 0}, prho = 0.0;   // pending row: q (West folded in), coef, new Density
+    double mwp[3] = {0, 0, 0}, mwpD = 0.0;                              // message from the pending row to the row East of it
+    unsigned char act_j = load_act(afirst);
+
+    // Row a: phase A of input row a, then finish row a - 1.  Rw, Rc, Re: input rows a-1, a, a+1 (clamped).
+    auto row = [&](int a, double* Rw, double* Rc, double* Re, bool first) {
+        double rn[NF2], rs[NF2], hx[NF2], pp[NF2];
+        if (TRIO_PRIO) __builtin_amdgcn_s_setprio(3);
+        if constexpr (STAGE > 0) {
+            if (first) {
+                // The row before the first: at the start of the domain the clamp-to-self rule makes it the first row
+                // itself; elsewhere the first row only sends its East message, which does not depend on the x slopes.
+                asm volatile("");
+                ring_row(a, Rc);
+#pragma unroll
+                for (int f = 0; f < NF2; ++f) Rw[f] = Rc[f];
+            }
+            ring_row(a + 1, Re);
+        }
+        x_half_slopes2(Rc, Re, Rw, hx);
+        if constexpr (STAGE == 0) {
+            load_row(clampr(a + 2), Rw);        // Rw is dead: the row two ahead goes into it
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) raw0[(a + 1) & 1][f][tl] = Re[f];
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) { rn[f] = raw0[a & 1][f][lnc]; rs[f] = raw0[a & 1][f][lsc]; }
+        } else {
+            const double* cen = ring_in + (size_t)slot3(clampr(a)) * (NF2 * NTS);
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) { rn[f] = cen[f * NTS + lnc]; rs[f] = cen[f * NTS + lsc]; }
+        }
+        const unsigned char act_n = load_act(clampr(a + 1));
+        const int r = a - 1;
+        const int rr = r < xs ? xs : r;         // a row the planes' descriptors can be built on
+        if constexpr (STAGE == 2 && FILTER) {
+            const PlaneRef q(fpp + (long)rr * plane5, pbytes);
+#pragma unroll
+            for (int f = 0; f < NF2; ++f) pp[f] = q.ld(vc, (unsigned)f * fstride);
+        }
+        StreamA2 A;
+        if (TRIO_PRIO) phaseA2s<SelMask, TrioPrioHook>(K, Rc, hx, rn, rs, mask_of(act_j != 0), A);
+        else phaseA2s(K, Rc, hx, rn, rs, mask_of(act_j != 0), A);
+        if (first) {        // clamp-to-self on the West side (a real branch: see sweep2d_stream)
+            asm volatile("");
+            mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwpD = A.me[S2_DYE];
+        }
+        stream_west(A.q, A.coef, mwp, mwpD);
+        double (*L)[NTS] = lmsg[a & 1];
+        L[0][tl] = A.ms[S2_U]; L[1][tl] = A.ms[S2_V]; L[2][tl] = A.ms[S2_T]; L[3][tl] = A.ms[S2_DYE];
+        L[4][tl] = A.mn[S2_U]; L[5][tl] = A.mn[S2_V];
+        // finish row r: pending values + East message + North / South messages of row r
+        const double (*P)[NTS] = lmsg[r & 1];
+        const double nU = stream_finish(pq[S2_U], pcoef[S2_U], A.me[S2_U], P[0][lnc], P[4][lsc]);
+        const double nV = stream_finish(pq[S2_V], pcoef[S2_V], A.me[S2_V], P[1][lnc], P[5][lsc]);
+        const double nT = stream_finish(pq[S2_T], pcoef[S2_T], A.me[S2_T], P[2][lnc], P[2][lsc]);
+        const double nD = stream_finish(pq[S2_DYE], pcoef[S2_DYE], A.me[S2_DYE], P[3][lnc], P[3][lsc]);
+        if constexpr (STAGE < 2) {
+            // Written unconditionally (straight-line code keeps the row's registers short-lived).  A row on which this
+            // stage's output is not defined -- the one before the first, one beyond the domain's end -- lands in the
+            // ring slot of a row three further on or back, which the consumer is not reading at that time: the slot
+            // is rewritten before row r + 3 is read, and row r - 3 was last read an iteration earlier.
+            double* o = ring_out + (size_t)slot3(r) * (NF2 * NTS) + tl;
+            o[F2_U * NTS] = nU; o[F2_V * NTS] = nV; o[F2_RHO * NTS] = prho; o[F2_T * NTS] = nT; o[F2_DYE * NTS] = nD;
+        } else {
+            const unsigned vs = (!first && r >= xs) ? vst : 0xFFFFFFF0u;
+            const PlaneRef d(dst + (long)rr * plane5, pbytes);
+            d.st_nt(vs, (unsigned)F2_RHO * fstride, prho);
+            d.st_nt(vs, (unsigned)F2_T * fstride, nT);
+            d.st_nt(vs, (unsigned)F2_U * fstride, nU);
+            d.st_nt(vs, (unsigned)F2_V * fstride, nV);
+            d.st_nt(vs, (unsigned)F2_DYE * fstride, nD);
+            if (FILTER) {
+                // Density and Temperature filtered in every cell; U, V, Dye where the cell is active (coef of U is
+                // zero exactly in the cells that keep their values) and otherwise the kept value itself: the slot
+                // that receives the filtered values is a buffer of its own here, not the slot the step started from
+                const PlaneRef pv(fprev + (long)rr * plane5, pbytes);
+                const lane_mask am = mask_of(pcoef[S2_U] != 0.0);
+                pv.st_nt(vs, (unsigned)F2_RHO * fstride, pp[F2_RHO] + (0.5 * (prho - pp[F2_RHO])));
+                pv.st_nt(vs, (unsigned)F2_T * fstride, pp[F2_T] + (0.5 * (nT - pp[F2_T])));
+                pv.st_nt(vs, (unsigned)F2_U * fstride, select(am, pp[F2_U] + (0.5 * (nU - pp[F2_U])), nU));
+                pv.st_nt(vs, (unsigned)F2_V * fstride, select(am, pp[F2_V] + (0.5 * (nV - pp[F2_V])), nV));
+                pv.st_nt(vs, (unsigned)F2_DYE * fstride, select(am, pp[F2_DYE] + (0.5 * (nD - pp[F2_DYE])), nD));
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { pq[f] = A.q[f]; pcoef[f] = A.coef[f]; }
+        prho = A.rho;
+        mwp[0] = A.mw[0]; mwp[1] = A.mw[1]; mwp[2] = A.mw[2]; mwpD = A.me[S2_DYE];
+        act_j = act_n;
+    };
+
+    if constexpr (STAGE == 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) load_row(clampr(afirst - 1 + u), R[u]);
+#pragma unroll
+        for (int f = 0; f < NF2; ++f) { raw0[afirst & 1][f][tl] = R[1][f]; raw0[(afirst + 1) & 1][f][tl] = R[1][f]; }
+    }
+    __syncthreads();
+    if constexpr (STAGE == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): see sweep2d_stream
+    int done = 0;
+    const int lead = afirst - (xs - 3 - 3 * STAGE);     // iterations before this stage's first row
+    for (; done < lead; ++done) __syncthreads();
+    int a = afirst;
+    if (a <= alast) {
+        row(a, R[0], R[1], R[2], true);
+        __syncthreads();
+        ++a; ++done;
+        while (a <= alast) {
+            row(a, R[1], R[2], R[0], false);
+            __syncthreads();
+            ++a; ++done;
+            if (a > alast) break;
+            row(a, R[2], R[0], R[1], false);
+            __syncthreads();
+            ++a; ++done;
+            if (a > alast) break;
+            row(a, R[0], R[1], R[2], false);
+            __syncthreads();
+            ++a; ++done;
+        }
+    }
+    for (; done < nit; ++done) __syncthreads();
+}
+
+template <int NTS, int MINW, bool FILTER>
+__global__ void __launch_bounds__(3 * NTS, MINW)
+sweep2d_trio(FastConsts K, const double* __restrict__ src, double* __restrict__ dst, const uint8_t* __restrict__ active,
+             int nx, int ny, int lo0, int hi0, int ch, int wmax, const double* __restrict__ fpp, double* __restrict__ fprev) {
+    extern __shared__ double smem[];
+    const int t = threadIdx.x;
+    const int first_lane = (int)__builtin_amdgcn_readfirstlane(t) & ~63;     // first lane of this wave (scalar)
+    const int stage = first_lane / NTS;
+    const int tl = t - stage * NTS, wave0 = first_lane - stage * NTS;
+    const TrioTiles tp = trio_tiles(ny, wmax);
+    const unsigned wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int bx = (int)(wg % (unsigned)tp.ntile), by = (int)(wg / (unsigned)tp.ntile);
+    const int ytile = trio_tile_start(tp, bx);
+    const int yend = bx + 1 < tp.ntile ? trio_tile_start(tp, bx + 1) : ny;
+    const int nv = (yend < ny ? yend : ny) - ytile;
+    const int xs = by * ch;
+    const int xe = xs + ch < nx ? xs + ch : nx;
+    if (stage == 0)
+        trio_stage<0, NTS, FILTER>(K, src, dst, active, nx, ny, lo0, hi0, xs, xe, ytile, nv, tl, wave0, fpp, fprev, smem);
+    else if (stage == 1)
+        trio_stage<1, NTS, FILTER>(K, src, dst, active, nx, ny, lo0, hi0, xs, xe, ytile, nv, tl, wave0, fpp, fprev, smem);
+    else
+        trio_stage<2, NTS, FILTER>(K, src, dst, active, nx, ny, lo0, hi0, xs, xe, ytile, nv, tl, wave0, fpp, fprev, smem);
+}
+
 // Tiled 3-D sweep.  A block owns a (TY-2) x (TZ-2) patch of (y, z) columns plus a one-cell halo
 // ring (lanes run along z, the contiguous index) and walks a chunk of x-planes.  As in the 2-D
 // tiled kernel each thread keeps its column's stored values and phase-A results for three
@@ -1779,6 +2043,22 @@ static int march_chunk(int nplanes, long tiles, long slots) {
     return best;
 }
 
+// x-planes per block of the three-sweeps kernel.  One block (nts == 256) or two (128) run on a compute unit at a time,
+// every block of a launch takes the same time per iteration, and a block of `ch` planes runs ch + 10 iterations
+// (the three stages follow one another three rows apart): the launch takes ceil(blocks / slots) rounds of that.
+static int trio_chunk_for(int nx, int ny, int nts, int cus) {
+    const long slots = (nts == 128 ? 2L : 1L) * cus, tiles = trio_tiles(ny, nts - 16).ntile;
+    int best = nx;
+    long best_cost = -1;
+    for (int nchunk = 1; nchunk <= nx; ++nchunk) {
+        const int ch = (nx + nchunk - 1) / nchunk;
+        if (ch < 8 && nchunk > 1) break;
+        const long cost = ((tiles * ((nx + ch - 1) / ch) + slots - 1) / slots) * (ch + 10);
+        if (best_cost < 0 || cost < best_cost) { best = ch; best_cost = cost; }
+    }
+    return best;
+}
+
 // The strict 2-D sweep without the filter, LEAN form, instantiated in cfd_strict2d_lean.hip (compiled with the
 // minimum-register scheduling strategy, under which it fits 256 registers: two waves per SIMD).
 extern "C" int cfd_internal_launch_strict2d_lean(const SweepConsts* K, const double* src, double* dst,
@@ -2031,6 +2311,73 @@ static int launch_pair(cfd_handle* h, const double* src, double* dst, const doub
     return CFD_OK;
 }
 
+// All three sweeps of a step (+ filter) in one pass; only where trio_ok(h).
+static bool trio_ok(const cfd_handle* h) {
+    const cfd_params& p = h->p;
+    return h->two_d && (p.flags & CFD_FLAG_FAST_MATH) && !(p.flags & CFD_FLAG_SIMPLE_KERNEL) && h->trio_enabled &&
+           h->variant < 0 && !(p.ghost_lo || p.ghost_hi);
+}
+
+// src: the slot the step starts from; dst: the slot that receives the step's result; fpp / fprev (both or neither):
+// the filter's older time level and the buffer that receives the filtered values of EVERY owned cell.
+static int launch_trio(cfd_handle* h, const double* src, double* dst, const double* fpp, double* fprev) {
+    const cfd_params& p = h->p;
+    EventPair ev{};
+    if (h->timing) {
+        if (h->ev_free.empty()) {
+            HIP_TRY(hipEventCreate(&ev.a));
+            HIP_TRY(hipEventCreate(&ev.b));
+        } else {
+            ev = h->ev_free.back();
+            h->ev_free.pop_back();
+        }
+    }
+    hipEvent_t ea = h->timing ? ev.a : nullptr, eb = h->timing ? ev.b : nullptr;
+    const uint8_t* act = h->d_active + GHOST * h->plane;
+    const int ch = h->trio_chunk, nts = h->trio_nts, wmax = nts - 16;
+    const TrioTiles tp = trio_tiles(p.ny, wmax);
+    const int nchunk = (p.nx + ch - 1) / ch;
+    const size_t lds = (size_t)TRIO_LDS_ROWS * nts * sizeof(double);
+    const int lo0 = 0, hi0 = p.nx - 1;
+#define LAUNCH_TRIO(NTS, MINW, FILT)                                                               \
+    do {                                                                                           \
+        auto kern = sweep2d_trio<NTS, MINW, FILT>;                                                 \
+        static bool attr_set[64] = {};                                                             \
+        if (lds > 64 * 1024 && !attr_set[h->device & 63]) {                                        \
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set[h->device & 63] = true;                                                       \
+        }                                                                                          \
+        hipExtLaunchKernelGGL(kern, dim3(tp.ntile * nchunk), dim3(3 * NTS), lds, h->stream, ea, eb, 0, h->KF, src,  \
+                              dst, act, p.nx, p.ny, lo0, hi0, ch, wmax, fpp, fprev);               \
+    } while (0)
+    if (nts == 128) { if (fpp) LAUNCH_TRIO(128, 3, true); else LAUNCH_TRIO(128, 3, false); }
+    else { if (fpp) LAUNCH_TRIO(256, 3, true); else LAUNCH_TRIO(256, 3, false); }
+#undef LAUNCH_TRIO
+    HIP_TRY(hipGetLastError());
+    if (h->timing) { ev.kind = 3; h->ev_used.push_back(ev); }
+    return CFD_OK;
+}
+
+// runSingleStep as one launch: the first sweep advances the time slot, the other two stay in it, then the filter
+// writes slot t-1.  That slot is the buffer the step started from, which other blocks still read, so the filtered
+// values go to the scratch buffer, which then takes that slot's place (the step's source buffer becomes scratch).
+static int step_trio(cfd_handle* h) {
+    const int nc = (h->cmt + 1) % 3;
+    const double* src = slot_base(h, h->cmt);
+    const bool filter = h->cat + 1 > 1;
+    int rc = launch_trio(h, src, slot_base(h, nc), filter ? slot_base(h, (h->cmt + 2) % 3) : nullptr,
+                         filter ? slot_base(h, 3) : nullptr);
+    if (rc) return rc;
+    if (filter) {
+        const int t = h->map[h->cmt];
+        h->map[h->cmt] = h->map[3];
+        h->map[3] = t;
+    }
+    h->cmt = nc;
+    h->cat += 1;
+    return CFD_OK;
+}
+
 extern "C" {
 
 const char* cfd_last_error(void) { return g_err.c_str(); }
@@ -2128,6 +2475,10 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
         if (h->pair_chunk < 32) h->pair_chunk = 32;
     }
     if (h->pair_chunk < 1) h->pair_chunk = 1;
+    h->trio_enabled = h->pair_enabled && (getenv("CFD_TRIO") ? atoi(getenv("CFD_TRIO")) != 0 : true);
+    h->trio_nts = getenv("CFD_TRIO_NTS") && atoi(getenv("CFD_TRIO_NTS")) == 128 ? 128 : 256;
+    h->trio_chunk = getenv("CFD_TRIO_CHUNK") ? atoi(getenv("CFD_TRIO_CHUNK")) : trio_chunk_for(p->nx, p->ny, h->trio_nts, h->cus);
+    if (h->trio_chunk < 1) h->trio_chunk = 1;
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
     h->chunk_auto = true;
@@ -2137,7 +2488,8 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
     h->ghost_mask_set = false;
     h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;
-    h->timing = false; h->t_ms[0] = h->t_ms[1] = h->t_ms[2] = 0.0; h->t_launches[0] = h->t_launches[1] = h->t_launches[2] = 0;
+    h->timing = false;
+    for (int kd = 0; kd < NKIND; ++kd) { h->t_ms[kd] = 0.0; h->t_launches[kd] = 0; }
     h->mew.assign(fields[5], fields[5] + n);
 
 #define CREATE_TRY(expr)                                                                       \
@@ -2349,13 +2701,12 @@ int cfd_step(cfd_handle* h, int nsteps) {
         // slot t-1 is not read by any sweep), so only the last of the three is applied -- inside
         // the third sweep's kernel where that kernel supports it, as its own launch otherwise.
         int rc;
-        if ((rc = cfd_sweep(h, 1))) return rc;
-        if (pair_ok(h) || !(h->p.ghost_lo || h->p.ghost_hi)) {
-            if ((rc = cfd_sweep_pair_and_filter(h))) return rc;
-        } else {
-            if ((rc = cfd_sweep(h, 0))) return rc;
-            if ((rc = cfd_sweep_and_filter(h))) return rc;
+        if (trio_ok(h)) {
+            if ((rc = step_trio(h))) return rc;
+            continue;
         }
+        if ((rc = cfd_sweep(h, 1))) return rc;
+        if ((rc = cfd_sweep_pair_and_filter(h))) return rc;     // falls back to two launches where it must
     }
     return CFD_OK;
 }
@@ -2598,7 +2949,7 @@ static int collect_timing(cfd_handle* h) {
 
 int cfd_kernel_timing(cfd_handle* h, int kind, double* total_ms, int64_t* launches, int reset) {
     if (!h) return fail(CFD_E_ARG, "cfd_kernel_timing: null handle");
-    if (kind < 0 || kind > 2) return fail(CFD_E_ARG, "cfd_kernel_timing: kind must be 0, 1 or 2");
+    if (kind < 0 || kind >= NKIND) return fail(CFD_E_ARG, "cfd_kernel_timing: kind must be 0, 1, 2 or 3");
     int rc = collect_timing(h);
     if (rc) return rc;
     if (total_ms) *total_ms = h->t_ms[kind];

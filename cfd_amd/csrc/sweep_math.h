@@ -750,7 +750,12 @@ CFD_HD double paired_of(const FluxDir& f, double u, double hu, double v, double 
     return fma(-2.0, hv, fma(f.S, p2, f.D * p1) - dmu_u);
 }
 
-template <class S = SelMask>
+// Progress hook: a kernel whose waves run the same row in lock-step can have a wave lower its issue priority as it
+// gets through the row (PhaseHook::at(1..3) after the x faces, the y faces and the messages), so that the waves
+// sharing a SIMD finish the row together instead of oldest first.
+struct NoPhaseHook { CFD_HD static void at(int) {} };
+
+template <class S = SelMask, class H = NoPhaseHook>
 CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[NF2],
                      const double n[NF2], const double s[NF2], typename S::mask act, StreamA2& o) {
     const double rho = c[F2_RHO], T = c[F2_T];
@@ -764,6 +769,7 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     div[E2_T] = k.rcx2 * flux_of(X, T, hx[F2_T]);
     div[E2_DYE] = k.rcx2 * flux_of(X, c[F2_DYE], hx[F2_DYE]);
     const double dea = visc_of(X, c[F2_U], hx[F2_U]), deb = visc_of(X, c[F2_V], hx[F2_V]);
+    H::at(1);
     // ---- y faces
     double hy[NF2];
     for (int q = 0; q < NF2; ++q) hy[q] = half_slope(n[q], c[q], s[q]);
@@ -775,6 +781,7 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     div[E2_DYE] = fma(k.rcy2, flux_of(Y, c[F2_DYE], hy[F2_DYE]), div[E2_DYE]);
     const double dna = visc_of(Y, c[F2_U], hy[F2_U]), dnb = visc_of(Y, c[F2_V], hy[F2_V]);
     const double qq = paired_of(Y, c[F2_U], hy[F2_U], c[F2_V], hy[F2_V], dna);
+    H::at(2);
     // ---- centre products
     const double muC = mu_stream(k, c[F2_T]);
     const double a = muC * c[F2_U], b = muC * c[F2_V], g = muC * c[F2_DYE];
@@ -794,6 +801,7 @@ CFD_HD void phaseA2s(const FastConsts& k, const double c[NF2], const double hx[N
     o.ms[S2_V] = fma(k.kxy, dea, syV);   o.mn[S2_V] = fma(-k.kxy, dea, syV);
     o.ms[S2_T] = k.kyy * py;
     o.ms[S2_DYE] = k.kyyd * g;
+    H::at(3);
     // ---- the cell's own part
     const double gU = fma(k.cUa, a, div[E2_U]), gV = fma(k.cVb, b, div[E2_V]);
     const double gT = fma(k.kxx2, px, fma(k.kyy2, py, k.cp * div[E2_T])), gD = fma(k.cDg, g, div[E2_DYE]);

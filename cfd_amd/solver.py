@@ -189,7 +189,7 @@ class AdjGraph:
 
     def kernel_timing(self, kind, reset=True):
         """(total milliseconds, launches) of kind 0 = plain sweeps, 1 = sweeps fused with the time filter,
-        2 = two sweeps and the filter in one pass."""
+        2 = two sweeps and the filter in one pass, 3 = a whole step (three sweeps and the filter) in one pass."""
         ms, n = ctypes.c_double(), ctypes.c_int64()
         check(self._lib.cfd_kernel_timing(self._h, int(kind), ctypes.byref(ms), ctypes.byref(n), int(bool(reset))))
         return ms.value, n.value

@@ -129,6 +129,59 @@ def test_two_sweeps_in_one_pass_equal_two_launches(shape, chunk, monkeypatch):
     assert ga.kernel_timing(2)[1] == 1 and ga.kernel_timing(1)[1] == 0
 
 
+@pytest.mark.parametrize("nts", [256, 128])
+@pytest.mark.parametrize("chunk", [1, 2, 3, 7, 64])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 5), (3, 300), (4, 1), (5, 17), (70, 241), (129, 37), (33, 480),
+                                   (40, 256), (23, 250)])
+def test_whole_step_in_one_pass_equals_three_launches(shape, chunk, nts, monkeypatch):
+    """cfd_step as ONE launch (all three sweeps of a step and the filter in one pass over memory, one group of
+    waves per sweep, the intermediate fields in LDS only) against cfd_sweep(1), cfd_sweep(0), cfd_sweep_and_filter:
+    bit-identical in all three slots from the first step (no filter yet) on; one row, one column, ragged and
+    several tiles, chunks shorter than the distance between the stages, inactive cells included."""
+    monkeypatch.setenv("CFD_TRIO_CHUNK", str(chunk))
+    monkeypatch.setenv("CFD_TRIO_NTS", str(nts))
+    monkeypatch.setenv("CFD_TRIO", "1")
+    params, fields, active = small_case(shape[0], shape[1], 1, 31)
+    ga = _gpu_graph(params, fields, active, 4)
+    monkeypatch.setenv("CFD_PAIR", "0")
+    gb = _gpu_graph(params, fields, active, 4)
+    for step in range(4):
+        ga.step(1)
+        gb.sweep(True); gb.sweep(False); gb.sweep_and_filter()
+        assert (ga.currModTime, ga.currAbsTime) == (gb.currModTime, gb.currAbsTime)
+        for rel in range(3):
+            fa, fb = ga.read_fields(rel), gb.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(fa[k], fb[k]), (step, rel, PROPS[k], float(np.max(np.abs(fa[k] - fb[k]))))
+    # and the launch really was the one-pass kernel
+    ga.set_timing(True)
+    ga.step(1); ga.sync()
+    assert ga.kernel_timing(3)[1] == 1 and ga.kernel_timing(0)[1] == 0 and ga.kernel_timing(2)[1] == 0
+
+
+def test_whole_step_in_one_pass_default_chunk_wide_grid():
+    """The same at the benchmark's width with the chunk length the library picks, plus the cavity walls (U = V = 0
+    exactly in the interior: the coefficient rule's other branch in every cell)."""
+    import os
+    from cfd_amd import cases
+    for params, fields, active in (small_case(300, 4096, 1, 37), cases.cavity_2d(96, 700)):
+        params = dict(params)
+        params["dt"] = 1e-7
+        ga = _gpu_graph(params, fields, active, 4)
+        os.environ["CFD_PAIR"] = "0"
+        try:
+            gb = _gpu_graph(params, fields, active, 4)
+        finally:
+            del os.environ["CFD_PAIR"]
+        ga.step(3)
+        for _ in range(3):
+            gb.sweep(True); gb.sweep(False); gb.sweep_and_filter()
+        for rel in range(3):
+            fa, fb = ga.read_fields(rel), gb.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(fa[k], fb[k]), (rel, PROPS[k], float(np.max(np.abs(fa[k] - fb[k]))))
+
+
 @pytest.mark.parametrize("chunk", [3, 32])
 @pytest.mark.parametrize("shape", [(70, 256), (37, 300), (50, 33), (9, 482), (21, 62), (21, 63), (130, 4096)])
 def test_narrow_last_tile_shares_blocks_bitwise(shape, chunk, monkeypatch):
