@@ -20,6 +20,7 @@ CFD_COMM_ID_BYTES = 128
 EXPORTS = [
     "cfd_default_params", "cfd_create", "cfd_destroy", "cfd_step", "cfd_sweep", "cfd_sweep_and_filter", "cfd_sweep_begin", "cfd_sweep_end", "cfd_sweep_begin_depth", "cfd_sweep_end_on", "cfd_sweep_pair_and_filter", "cfd_time_filter",
     "cfd_total_density", "cfd_total_density_noalloc", "cfd_read_fields", "cfd_write_fields", "cfd_set_time", "cfd_property_slice", "cfd_time", "cfd_last_error", "cfd_halo_planes", "cfd_halo_planes_depth", "cfd_set_ghost_active", "cfd_pair_available",
+    "cfd_set_ghost_active_depth", "cfd_one_pass_step_available", "cfd_step_one_pass", "cfd_step_one_pass_begin", "cfd_step_one_pass_end_on",
     "cfd_multi_create", "cfd_multi_create_rank", "cfd_comm_unique_id", "cfd_multi_destroy", "cfd_multi_step", "cfd_multi_total_density",
     "cfd_multi_read_fields", "cfd_multi_time", "cfd_multi_sync", "cfd_multi_info", "cfd_multi_slab", "cfd_rccl_selftest",
     "cfd_stream", "cfd_set_stream", "cfd_kernel_name", "cfd_sync", "cfd_set_timing", "cfd_sweep_timing", "cfd_kernel_timing", "cfd_live_fields",
@@ -90,6 +91,11 @@ def load():
     L.cfd_halo_planes_depth.argtypes = [H, ctypes.c_int, PP, PP, PP, PP, ctypes.POINTER(ctypes.c_size_t)]
     L.cfd_set_ghost_active.argtypes = [H, ctypes.c_void_p, ctypes.c_void_p]
     L.cfd_pair_available.argtypes = [H, ctypes.POINTER(ctypes.c_int)]
+    L.cfd_set_ghost_active_depth.argtypes = [H, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.cfd_one_pass_step_available.argtypes = [H, ctypes.POINTER(ctypes.c_int)]
+    L.cfd_step_one_pass.argtypes = [H]
+    L.cfd_step_one_pass_begin.argtypes = [H]
+    L.cfd_step_one_pass_end_on.argtypes = [H, ctypes.c_void_p]
     L.cfd_stream.argtypes = [H, PP]
     L.cfd_sync.argtypes = [H]
     L.cfd_set_stream.argtypes = [H, ctypes.c_void_p]

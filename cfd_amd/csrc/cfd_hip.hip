@@ -7,7 +7,8 @@
 // plain structure of arrays, while a whole x-plane of all fields is ONE contiguous run: the
 // slab halo that a neighbouring GPU needs is a single message with no pack kernel.  Planes -2, -1
 // and nx, nx+1 are ghost planes (used only when a neighbouring slab exists: one per side for a
-// single sweep, two for the kernel that does two sweeps in one pass).
+// single sweep, two for the kernel that does two sweeps in one pass, three -- planes -3 and nx+2 too --
+// for the kernel that does a whole step in one pass).
 //
 // Four buffers per handle: the three time slots of the reference plus one scratch slot that
 // receives a sweep which does not advance time (the reference rebuilds slot t from a snapshot
@@ -30,7 +31,7 @@ using namespace cfd;
 // CFD_KERNEL_TEMPLATES_ONLY: a second translation unit (cfd_strict2d_lean.hip) includes this file for the kernel
 // templates alone and instantiates one of them under other compiler options.
 #ifndef CFD_KERNEL_TEMPLATES_ONLY
-static constexpr int GHOST = 2;      // ghost x-planes allocated on either side of the owned planes
+static constexpr int GHOST = 3;      // ghost x-planes allocated on either side of the owned planes
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -71,7 +72,7 @@ struct cfd_handle {
     double* buf[4];         // three time slots + scratch
     int map[4];             // map[t] = buffer holding time slot t (t = 0..2); map[3] = scratch
     uint8_t* d_active;      // (nx + 2*GHOST) * plane bytes; ghost planes zero until cfd_set_ghost_active
-    bool ghost_mask_set;    // the masks of planes -1 and nx have been supplied
+    int ghost_mask_depth;   // planes per side whose neighbour masks have been supplied (0, 1 or 2)
     double* d_partial;      // reduction partials
     int n_partial;
     std::vector<double> mew;   // stored Mew: set at creation, never read by the update
@@ -94,6 +95,8 @@ struct cfd_handle {
     // a sweep split into cfd_sweep_begin / cfd_sweep_end
     struct {
         bool open, step_time, with_filter, fused;
+        bool trio;          // the open call is cfd_step_one_pass_begin: c0, c1 = the chunks it launched
+        int c0, c1;
         const double* src;
         double* dst;
         const double* fpp;
@@ -1393,7 +1396,8 @@ __device__ __forceinline__ void trio_stage(const FastConsts& K, const double* __
 template <int NTS, int MINW, bool FILTER>
 __global__ void __launch_bounds__(3 * NTS, MINW)
 sweep2d_trio(FastConsts K, const double* __restrict__ src, double* __restrict__ dst, const uint8_t* __restrict__ active,
-             int nx, int ny, int lo0, int hi0, int ch, int wmax, const double* __restrict__ fpp, double* __restrict__ fprev) {
+             int nx, int ny, int lo0, int hi0, int ch, int by0, int wmax, const double* __restrict__ fpp,
+             double* __restrict__ fprev) {
     extern __shared__ double smem[];
     const int t = threadIdx.x;
     const int first_lane = (int)__builtin_amdgcn_readfirstlane(t) & ~63;     // first lane of this wave (scalar)
@@ -1401,7 +1405,7 @@ sweep2d_trio(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     const int tl = t - stage * NTS, wave0 = first_lane - stage * NTS;
     const TrioTiles tp = trio_tiles(ny, wmax);
     const unsigned wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int bx = (int)(wg % (unsigned)tp.ntile), by = (int)(wg / (unsigned)tp.ntile);
+    const int bx = (int)(wg % (unsigned)tp.ntile), by = by0 + (int)(wg / (unsigned)tp.ntile);
     const int ytile = trio_tile_start(tp, bx);
     const int yend = bx + 1 < tp.ntile ? trio_tile_start(tp, bx + 1) : ny;
     const int nv = (yend < ny ? yend : ny) - ytile;
@@ -2275,7 +2279,7 @@ static bool pair_ok(const cfd_handle* h) {
     // (the planes it sends two-deep to a neighbour must be its own)
     const bool ghosts = p.ghost_lo || p.ghost_hi;
     return h->two_d && (p.flags & CFD_FLAG_FAST_MATH) && !(p.flags & CFD_FLAG_SIMPLE_KERNEL) && h->pair_enabled &&
-           h->variant < 0 && (!ghosts || (h->ghost_mask_set && p.nx >= 2));
+           h->variant < 0 && (!ghosts || (h->ghost_mask_depth >= 1 && p.nx >= 2));
 }
 
 static int launch_pair(cfd_handle* h, const double* src, double* dst, const double* fpp, double* fprev) {
@@ -2314,13 +2318,18 @@ static int launch_pair(cfd_handle* h, const double* src, double* dst, const doub
 // All three sweeps of a step (+ filter) in one pass; only where trio_ok(h).
 static bool trio_ok(const cfd_handle* h) {
     const cfd_params& p = h->p;
+    // a slab needs the masks of two ghost planes per side and at least three planes (the planes it sends
+    // three-deep to a neighbour must be its own)
+    const bool ghosts = p.ghost_lo || p.ghost_hi;
     return h->two_d && (p.flags & CFD_FLAG_FAST_MATH) && !(p.flags & CFD_FLAG_SIMPLE_KERNEL) && h->trio_enabled &&
-           h->variant < 0 && !(p.ghost_lo || p.ghost_hi);
+           h->variant < 0 && (!ghosts || (h->ghost_mask_depth >= 2 && p.nx >= 3));
 }
 
 // src: the slot the step starts from; dst: the slot that receives the step's result; fpp / fprev (both or neither):
 // the filter's older time level and the buffer that receives the filtered values of EVERY owned cell.
-static int launch_trio(cfd_handle* h, const double* src, double* dst, const double* fpp, double* fprev) {
+// c0, c1: the range of chunks (of h->trio_chunk planes) to launch; c1 < 0: all of them.
+static int launch_trio(cfd_handle* h, const double* src, double* dst, const double* fpp, double* fprev, int c0 = 0,
+                       int c1 = -1) {
     const cfd_params& p = h->p;
     EventPair ev{};
     if (h->timing) {
@@ -2337,8 +2346,11 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
     const int ch = h->trio_chunk, nts = h->trio_nts, wmax = nts - 16;
     const TrioTiles tp = trio_tiles(p.ny, wmax);
     const int nchunk = (p.nx + ch - 1) / ch;
+    if (c1 < 0) c1 = nchunk;
+    if (c1 <= c0) return CFD_OK;        // empty range: nothing launched
     const size_t lds = (size_t)TRIO_LDS_ROWS * nts * sizeof(double);
-    const int lo0 = 0, hi0 = p.nx - 1;
+    // with a neighbouring slab the stored values reach three ghost planes out
+    const int lo0 = p.ghost_lo ? -3 : 0, hi0 = p.ghost_hi ? p.nx + 2 : p.nx - 1;
 #define LAUNCH_TRIO(NTS, MINW, FILT)                                                               \
     do {                                                                                           \
         auto kern = sweep2d_trio<NTS, MINW, FILT>;                                                 \
@@ -2347,8 +2359,8 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr_set[h->device & 63] = true;                                                       \
         }                                                                                          \
-        hipExtLaunchKernelGGL(kern, dim3(tp.ntile * nchunk), dim3(3 * NTS), lds, h->stream, ea, eb, 0, h->KF, src,  \
-                              dst, act, p.nx, p.ny, lo0, hi0, ch, wmax, fpp, fprev);               \
+        hipExtLaunchKernelGGL(kern, dim3(tp.ntile * (c1 - c0)), dim3(3 * NTS), lds, h->stream, ea, eb, 0, h->KF,    \
+                              src, dst, act, p.nx, p.ny, lo0, hi0, ch, c0, wmax, fpp, fprev);      \
     } while (0)
     if (nts == 128) { if (fpp) LAUNCH_TRIO(128, 3, true); else LAUNCH_TRIO(128, 3, false); }
     else { if (fpp) LAUNCH_TRIO(256, 3, true); else LAUNCH_TRIO(256, 3, false); }
@@ -2361,13 +2373,14 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
 // runSingleStep as one launch: the first sweep advances the time slot, the other two stay in it, then the filter
 // writes slot t-1.  That slot is the buffer the step started from, which other blocks still read, so the filtered
 // values go to the scratch buffer, which then takes that slot's place (the step's source buffer becomes scratch).
-static int step_trio(cfd_handle* h) {
+// c0, c1: chunk range as in launch_trio; finish: this call completes the step (slot rotation, time counters).
+static int step_trio(cfd_handle* h, int c0 = 0, int c1 = -1, bool finish = true) {
     const int nc = (h->cmt + 1) % 3;
     const double* src = slot_base(h, h->cmt);
     const bool filter = h->cat + 1 > 1;
     int rc = launch_trio(h, src, slot_base(h, nc), filter ? slot_base(h, (h->cmt + 2) % 3) : nullptr,
-                         filter ? slot_base(h, 3) : nullptr);
-    if (rc) return rc;
+                         filter ? slot_base(h, 3) : nullptr, c0, c1);
+    if (rc || !finish) return rc;
     if (filter) {
         const int t = h->map[h->cmt];
         h->map[h->cmt] = h->map[3];
@@ -2486,7 +2499,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     h->variant = -1;
     if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
-    h->ghost_mask_set = false;
+    h->ghost_mask_depth = 0;
     h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;
     h->timing = false;
     for (int kd = 0; kd < NKIND; ++kd) { h->t_ms[kd] = 0.0; h->t_launches[kd] = 0; }
@@ -2630,6 +2643,7 @@ int cfd_sweep_begin_depth(cfd_handle* h, int step_time, int with_filter, int edg
     if (edge_planes < 1) return fail(CFD_E_ARG, "cfd_sweep_begin_depth: edge_planes must be >= 1");
     HIP_TRY(hipSetDevice(h->device));
     auto& q = h->pend;
+    q.trio = false;
     q.step_time = step_time != 0;
     q.with_filter = with_filter != 0;
     q.fused = false;
@@ -2660,7 +2674,7 @@ int cfd_sweep_end(cfd_handle* h) {
 
 int cfd_sweep_end_on(cfd_handle* h, void* stream) {
     if (!h) return fail(CFD_E_ARG, "cfd_sweep_end: null handle");
-    if (!h->pend.open) return fail(CFD_E_STATE, "cfd_sweep_end: no split sweep is open");
+    if (!h->pend.open || h->pend.trio) return fail(CFD_E_STATE, "cfd_sweep_end: no split sweep is open");
     HIP_TRY(hipSetDevice(h->device));
     auto& q = h->pend;
     if (q.with_filter && (hipStream_t)stream != h->stream)
@@ -2850,7 +2864,7 @@ int cfd_time(cfd_handle* h, int* cmt, int* cat) {
 int cfd_halo_planes_depth(cfd_handle* h, int depth, void** send_lo, void** send_hi, void** recv_lo, void** recv_hi,
                           size_t* bytes) {
     if (!h) return fail(CFD_E_ARG, "cfd_halo_planes_depth: null handle");
-    if (depth < 1 || depth > GHOST) return fail(CFD_E_ARG, "cfd_halo_planes_depth: depth must be 1 or 2");
+    if (depth < 1 || depth > GHOST) return fail(CFD_E_ARG, "cfd_halo_planes_depth: depth must be 1, 2 or 3");
     if (depth > h->p.nx) return fail(CFD_E_ARG, "cfd_halo_planes_depth: the slab has fewer planes than the depth asked for");
     double* base = slot_base(h, h->cmt);
     const size_t pe = (size_t)h->nf * h->plane;
@@ -2869,23 +2883,87 @@ int cfd_halo_planes(cfd_handle* h, void** send_lo, void** send_hi, void** recv_l
 }
 
 int cfd_set_ghost_active(cfd_handle* h, const uint8_t* lo_plane, const uint8_t* hi_plane) {
+    return cfd_set_ghost_active_depth(h, 1, lo_plane, hi_plane);
+}
+
+int cfd_set_ghost_active_depth(cfd_handle* h, int depth, const uint8_t* lo_planes, const uint8_t* hi_planes) {
     if (!h) return fail(CFD_E_ARG, "cfd_set_ghost_active: null handle");
-    if ((h->p.ghost_lo && !lo_plane) || (h->p.ghost_hi && !hi_plane))
-        return fail(CFD_E_ARG, "cfd_set_ghost_active: a mask plane is needed on every side that has a ghost plane");
+    if (depth < 1 || depth > 2) return fail(CFD_E_ARG, "cfd_set_ghost_active_depth: depth must be 1 or 2");
+    if ((h->p.ghost_lo && !lo_planes) || (h->p.ghost_hi && !hi_planes))
+        return fail(CFD_E_ARG, "cfd_set_ghost_active: mask planes are needed on every side that has a ghost plane");
     if (h->pend.open) return fail(CFD_E_STATE, "cfd_set_ghost_active: a split sweep is open (call cfd_sweep_end first)");
     HIP_TRY(hipSetDevice(h->device));
     uint8_t* own = h->d_active + GHOST * h->plane;
-    if (h->p.ghost_lo) HIP_TRY(hipMemcpyAsync(own - h->plane, lo_plane, h->plane, hipMemcpyHostToDevice, h->stream));
+    const size_t bytes = (size_t)depth * h->plane;
+    // both in ascending x: lo_planes = planes -depth .. -1, hi_planes = planes nx .. nx + depth - 1
+    if (h->p.ghost_lo) HIP_TRY(hipMemcpyAsync(own - bytes, lo_planes, bytes, hipMemcpyHostToDevice, h->stream));
     if (h->p.ghost_hi)
-        HIP_TRY(hipMemcpyAsync(own + (size_t)h->p.nx * h->plane, hi_plane, h->plane, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(own + (size_t)h->p.nx * h->plane, hi_planes, bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->ghost_mask_set = true;
+    h->ghost_mask_depth = depth;
     return CFD_OK;
 }
 
 int cfd_pair_available(cfd_handle* h, int* available) {
     if (!h || !available) return fail(CFD_E_ARG, "cfd_pair_available: null pointer");
     *available = pair_ok(h) ? 1 : 0;
+    return CFD_OK;
+}
+
+int cfd_one_pass_step_available(cfd_handle* h, int* available) {
+    if (!h || !available) return fail(CFD_E_ARG, "cfd_one_pass_step_available: null pointer");
+    *available = trio_ok(h) ? 1 : 0;
+    return CFD_OK;
+}
+
+int cfd_step_one_pass(cfd_handle* h) {
+    if (!h) return fail(CFD_E_ARG, "cfd_step_one_pass: null handle");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_step_one_pass: a split sweep or step is open");
+    if (!trio_ok(h)) return fail(CFD_E_STATE, "cfd_step_one_pass: not available for this handle (see cfd_one_pass_step_available)");
+    HIP_TRY(hipSetDevice(h->device));
+    return step_trio(h);
+}
+
+// Chunks of the one-pass step whose blocks read owned planes only: a block of planes [xs, xe) reads planes xs - 3 .. xe + 2.
+static void trio_interior_chunks(const cfd_handle* h, int* c0, int* c1) {
+    const int ch = h->trio_chunk, nx = h->p.nx, nchunk = (nx + ch - 1) / ch;
+    int a = 0, b = nchunk;
+    if (h->p.ghost_lo) a = (3 + ch - 1) / ch;                   // first chunk with xs >= 3
+    if (h->p.ghost_hi) while (b > a && ((b * ch < nx ? b * ch : nx) + 2 > nx - 1)) --b;    // chunks with xe + 2 <= nx - 1
+    if (a > nchunk) a = nchunk;
+    if (b < a) b = a;
+    *c0 = a;
+    *c1 = b;
+}
+
+int cfd_step_one_pass_begin(cfd_handle* h) {
+    if (!h) return fail(CFD_E_ARG, "cfd_step_one_pass_begin: null handle");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_step_one_pass_begin: a split sweep or step is already open");
+    if (!trio_ok(h)) return fail(CFD_E_STATE, "cfd_step_one_pass_begin: not available for this handle (see cfd_one_pass_step_available)");
+    HIP_TRY(hipSetDevice(h->device));
+    auto& q = h->pend;
+    trio_interior_chunks(h, &q.c0, &q.c1);
+    int rc = step_trio(h, q.c0, q.c1, false);
+    if (rc) return rc;
+    q.trio = true;
+    q.open = true;
+    return CFD_OK;
+}
+
+int cfd_step_one_pass_end_on(cfd_handle* h, void* stream) {
+    if (!h) return fail(CFD_E_ARG, "cfd_step_one_pass_end_on: null handle");
+    if (!h->pend.open || !h->pend.trio) return fail(CFD_E_STATE, "cfd_step_one_pass_end_on: no split step is open");
+    HIP_TRY(hipSetDevice(h->device));
+    auto& q = h->pend;
+    const int nchunk = (h->p.nx + h->trio_chunk - 1) / h->trio_chunk;
+    const hipStream_t own = h->stream;
+    h->stream = (hipStream_t)stream;
+    int rc = step_trio(h, 0, q.c0, false);
+    if (!rc) rc = step_trio(h, q.c1, nchunk, true);     // an empty range still completes the step
+    h->stream = own;
+    if (rc) return rc;
+    q.open = false;
+    q.trio = false;
     return CFD_OK;
 }
 

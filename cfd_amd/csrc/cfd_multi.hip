@@ -76,6 +76,7 @@ struct cfd_multi {
     int world = 1;              // slabs along x, in all processes
     int transport = CFD_TRANSPORT_COPY;
     bool pair = false;          // the step's tail runs as one pass on every slab
+    bool trio = false;          // the whole step runs as one pass on every slab (one three-plane exchange per step)
     bool overlap = true;
     size_t plane = 0;
     std::vector<Slab> slab;     // the slabs this process holds, in rank order
@@ -163,6 +164,26 @@ int sweep_all(cfd_multi* m, int step_time, int with_filter) {
 int step_once(cfd_multi* m) {
     if (m->world == 1) {
         for (Slab& s : m->slab) M_CFD(cfd_step(s.h, 1));
+        M_CFD(record(m, false));
+    } else if (m->trio && !m->overlap) {
+        M_CFD(exchange(m, 3, false, READY_DONE));
+        for (Slab& s : m->slab) M_CFD(cfd_step_one_pass(s.h));
+        M_CFD(record(m, false));
+    } else if (m->trio) {
+        // ONE exchange per step, three planes deep, on the side stream beside the blocks that read owned planes only;
+        // the blocks next to a neighbour follow it on the side stream; the compute stream then waits for the side stream
+        for (Slab& s : m->slab) {
+            M_HIP(hipSetDevice(s.device));
+            M_HIP(hipStreamWaitEvent(side_of(m, s), s.done, 0));    // the previous step of this slab
+        }
+        M_CFD(exchange(m, 3, true, READY_DONE));
+        for (Slab& s : m->slab) M_CFD(cfd_step_one_pass_begin(s.h));
+        for (Slab& s : m->slab) M_CFD(cfd_step_one_pass_end_on(s.h, (void*)side_of(m, s)));
+        for (Slab& s : m->slab) {
+            M_HIP(hipSetDevice(s.device));
+            M_HIP(hipEventRecord(s.side_done, side_of(m, s)));
+            M_HIP(hipStreamWaitEvent(main_of(m, s), s.side_done, 0));
+        }
         M_CFD(record(m, false));
     } else if (!m->pair) {
         M_CFD(sweep_all(m, 1, 0));
@@ -343,17 +364,24 @@ int cfd_multi_create(const cfd_params* p, int n_slabs, const int32_t* devices, i
     // every slab learns its neighbours' masks of the adjoining planes (the one-pass tail needs them), then the
     // slabs agree on the form of a step
     if (rc == CFD_OK && n_slabs > 1) {
-        bool pair = true;
+        bool pair = true, trio = true;
+        // masks two planes deep where every neighbour has two planes to show
+        bool deep = true;
+        for (int i = 0; i < n_slabs; ++i) deep = deep && (m->slab[i].x1 - m->slab[i].x0 >= 2);
+        const int depth = deep ? 2 : 1;
         for (int i = 0; i < n_slabs && rc == CFD_OK; ++i) {
             const Slab& s = m->slab[i];
-            const uint8_t* lo = i > 0 ? active + (size_t)(s.x0 - 1) * m->plane : nullptr;
+            const uint8_t* lo = i > 0 ? active + (size_t)(s.x0 - depth) * m->plane : nullptr;
             const uint8_t* hi = i < n_slabs - 1 ? active + (size_t)s.x1 * m->plane : nullptr;
-            rc = cfd_set_ghost_active(s.h, lo, hi);
-            int ok = 0;
+            rc = cfd_set_ghost_active_depth(s.h, depth, lo, hi);
+            int ok = 0, ok3 = 0;
             if (rc == CFD_OK) rc = cfd_pair_available(s.h, &ok);
+            if (rc == CFD_OK) rc = cfd_one_pass_step_available(s.h, &ok3);
             pair = pair && ok;
+            trio = trio && ok3;
         }
         m->pair = pair && env_flag("CFD_MULTI_PAIR", true);
+        m->trio = trio && m->pair && env_flag("CFD_MULTI_TRIO", true);
     }
     if (rc != CFD_OK) { cfd_multi_destroy(m); return rc; }
     *out = m;
@@ -410,29 +438,32 @@ int cfd_multi_create_rank(const cfd_params* p, int rank, int world, const void* 
         if (r != ncclSuccess) return cleanup(fail(CFD_E_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)));
     }
     // agree on the 2-D form: minimum over the ranks of "my W is identically +0"
-    int mine = p->nz == 1 && !(p->flags & CFD_FLAG_FORCE_3D) && w_identically_zero(fields[2], (size_t)p->nx * m->plane);
-    int all = mine;
+    // ... and on how deep the neighbours' masks go: two planes where every rank has two planes to show
+    int mine[2] = {p->nz == 1 && !(p->flags & CFD_FLAG_FORCE_3D) && w_identically_zero(fields[2], (size_t)p->nx * m->plane),
+                   p->nx >= 2};
+    int all[2] = {mine[0], mine[1]};
     if ((rc = streams_for(m, dev, &s.ds)) != CFD_OK) return cleanup(rc);
     st = main_of(m, s);
     if (world > 1) {
-        if (hipMalloc((void**)&d_flag, sizeof(int)) != hipSuccess ||
-            hipMemcpyAsync(d_flag, &mine, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+        if (hipMalloc((void**)&d_flag, 2 * sizeof(int)) != hipSuccess ||
+            hipMemcpyAsync(d_flag, mine, 2 * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
             return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: device buffer for the agreement failed"));
-        ncclResult_t r = ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, s.comm, st);
+        ncclResult_t r = ncclAllReduce(d_flag, d_flag, 2, ncclInt, ncclMin, s.comm, st);
         if (r != ncclSuccess) return cleanup(fail(CFD_E_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r)));
-        if (hipMemcpyAsync(&all, d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (hipMemcpyAsync(all, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
             return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: reading the agreement back failed"));
     }
-    const int extra = all ? 0 : (p->nz == 1 ? CFD_FLAG_FORCE_3D : 0);
+    const int extra = all[0] ? 0 : (p->nz == 1 ? CFD_FLAG_FORCE_3D : 0);
+    const int depth = all[1] ? 2 : 1;
     if ((rc = make_slab(m, s, fields, active, extra)) != CFD_OK) return cleanup(rc);
     if (world > 1) {
-        // neighbours swap the masks of their first / last plane
-        const size_t pb = m->plane;
+        // neighbours swap the masks of their first / last `depth` planes
+        const size_t pb = (size_t)depth * m->plane;
         if (hipMalloc((void**)&d_first, pb) != hipSuccess || hipMalloc((void**)&d_last, pb) != hipSuccess ||
             hipMalloc((void**)&d_mlo, pb) != hipSuccess || hipMalloc((void**)&d_mhi, pb) != hipSuccess ||
             hipMemcpyAsync(d_first, active, pb, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(d_last, active + (size_t)(p->nx - 1) * pb, pb, hipMemcpyHostToDevice, st) != hipSuccess)
+            hipMemcpyAsync(d_last, active + (size_t)(p->nx - depth) * m->plane, pb, hipMemcpyHostToDevice, st) != hipSuccess)
             return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: device buffers for the mask planes failed"));
         ncclResult_t r = ncclGroupStart();
         if (r == ncclSuccess && rank > 0) r = ncclSend(d_first, pb, ncclUint8, rank - 1, s.comm, st);
@@ -446,19 +477,23 @@ int cfd_multi_create_rank(const cfd_params* p, int rank, int world, const void* 
             (rank < world - 1 && hipMemcpyAsync(hi.data(), d_mhi, pb, hipMemcpyDeviceToHost, st) != hipSuccess) ||
             hipStreamSynchronize(st) != hipSuccess)
             return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: reading the mask planes back failed"));
-        if ((rc = cfd_set_ghost_active(s.h, rank > 0 ? lo.data() : nullptr, rank < world - 1 ? hi.data() : nullptr)) != CFD_OK)
+        if ((rc = cfd_set_ghost_active_depth(s.h, depth, rank > 0 ? lo.data() : nullptr,
+                                             rank < world - 1 ? hi.data() : nullptr)) != CFD_OK)
             return cleanup(rc);
-        int ok = 0;
-        if ((rc = cfd_pair_available(s.h, &ok)) != CFD_OK) return cleanup(rc);
-        ok = ok && env_flag("CFD_MULTI_PAIR", true);
-        if (hipMemcpyAsync(d_flag, &ok, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+        int ok[2] = {0, 0};
+        if ((rc = cfd_pair_available(s.h, &ok[0])) != CFD_OK) return cleanup(rc);
+        if ((rc = cfd_one_pass_step_available(s.h, &ok[1])) != CFD_OK) return cleanup(rc);
+        ok[0] = ok[0] && env_flag("CFD_MULTI_PAIR", true);
+        ok[1] = ok[1] && ok[0] && env_flag("CFD_MULTI_TRIO", true);
+        if (hipMemcpyAsync(d_flag, ok, 2 * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
             return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: agreement on the step form failed"));
-        r = ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, s.comm, st);
+        r = ncclAllReduce(d_flag, d_flag, 2, ncclInt, ncclMin, s.comm, st);
         if (r != ncclSuccess) return cleanup(fail(CFD_E_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r)));
-        if (hipMemcpyAsync(&ok, d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (hipMemcpyAsync(ok, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
             return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: agreement on the step form failed"));
-        m->pair = ok != 0;
+        m->pair = ok[0] != 0;
+        m->trio = ok[1] != 0;
     }
     cleanup(CFD_OK);
     *out = m;
@@ -529,7 +564,7 @@ int cfd_multi_time(cfd_multi* m, int* curr_mod_time, int* curr_abs_time) {
 int cfd_multi_info(cfd_multi* m, int* local_slabs, int* one_pass_tail, int* overlapped) {
     if (!m) return fail(CFD_E_ARG, "cfd_multi_info: null handle");
     if (local_slabs) *local_slabs = (int)m->slab.size();
-    if (one_pass_tail) *one_pass_tail = m->pair ? 1 : 0;
+    if (one_pass_tail) *one_pass_tail = m->trio ? 2 : (m->pair ? 1 : 0);
     if (overlapped) *overlapped = (m->pair && m->overlap && m->world > 1) ? 1 : 0;
     return CFD_OK;
 }

@@ -111,10 +111,11 @@ class MultiGraph:
     currAbsTime = property(lambda self: self._time()[1])
 
     def info(self):
-        """(local slabs, tail of a step in one pass, exchanges beside the interior planes)"""
+        """(local slabs; 2 = the whole step is one pass with one exchange, 1 = the step's tail is one pass, 0 = three
+        sweeps with an exchange each; exchanges beside the interior planes)"""
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(self._lib.cfd_multi_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        return a.value, bool(b.value), bool(c.value)
+        return a.value, b.value, bool(c.value)
 
     def slab(self, i):
         h, x0, x1 = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()

@@ -203,17 +203,37 @@ class AdjGraph:
                                               ctypes.byref(nbytes)))
         return [x.value or 0 for x in p], nbytes.value
 
-    def set_ghost_active(self, lo_plane, hi_plane):
-        """Masks of the neighbouring slabs' planes next to this slab (None where there is no neighbour)."""
+    def set_ghost_active(self, lo_planes, hi_planes, depth=1):
+        """Masks of the neighbouring slabs' `depth` (1 or 2) planes next to this slab, each side in ascending x
+        (None where there is no neighbour)."""
         def arr(a):
             return None if a is None else np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
-        lo, hi = arr(lo_plane), arr(hi_plane)
+        lo, hi = arr(lo_planes), arr(hi_planes)
         plane = self._p.ny * self._p.nz
         for a in (lo, hi):
-            if a is not None and a.size != plane:
-                raise ValueError("a mask plane has ny*nz entries")
-        check(self._lib.cfd_set_ghost_active(self._h, None if lo is None else lo.ctypes.data,
-                                             None if hi is None else hi.ctypes.data))
+            if a is not None and a.size != depth * plane:
+                raise ValueError("a mask has depth*ny*nz entries")
+        check(self._lib.cfd_set_ghost_active_depth(self._h, int(depth), None if lo is None else lo.ctypes.data,
+                                                   None if hi is None else hi.ctypes.data))
+        return self
+
+    def one_pass_step_available(self):
+        """True if a whole step (three sweeps and the filter) runs as one pass over memory for this graph as it is now."""
+        v = ctypes.c_int()
+        check(self._lib.cfd_one_pass_step_available(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
+    def step_one_pass(self):
+        """runSingleStep as one launch (a slab: after a three-plane exchange)."""
+        check(self._lib.cfd_step_one_pass(self._h))
+        return self
+
+    def step_one_pass_begin(self):
+        check(self._lib.cfd_step_one_pass_begin(self._h))
+        return self
+
+    def step_one_pass_end(self, stream=None):
+        check(self._lib.cfd_step_one_pass_end_on(self._h, ctypes.c_void_p(self.stream() if stream is None else stream)))
         return self
 
     def pair_available(self):

@@ -102,7 +102,8 @@ void cfd_destroy(cfd_handle *h);
 /* runSingleStep (src/Main.hs:192-200), nsteps times: three sweeps, the first advancing the
  * time slot, each followed by the time filter.  Only the third filter of a step is live (the
  * first two are overwritten from the same inputs), so it is applied once, fused into the third
- * sweep's kernel; results are identical to cfd_sweep x3 + cfd_time_filter x3.
+ * sweep's kernel; results are identical to cfd_sweep x3 + cfd_time_filter x3.  On 2-D grids with
+ * CFD_FLAG_FAST_MATH the whole step is one launch (three sweeps and the filter in one pass over memory).
  * A slab (ghost_lo or ghost_hi set) needs its ghost planes exchanged before every sweep, which one
  * call for a whole step cannot do: CFD_E_STATE; drive a slab sweep by sweep (see the halo section). */
 int cfd_step(cfd_handle *h, int nsteps);
@@ -226,10 +227,10 @@ const char *cfd_last_error(void);
 int cfd_halo_planes(cfd_handle *h, void **send_lo, void **send_hi, void **recv_lo,
                     void **recv_hi, size_t *plane_bytes);
 
-/* The same for a halo `depth` planes deep (1 or 2): send_lo = the first `depth` owned planes, send_hi =
+/* The same for a halo `depth` planes deep (1, 2 or 3): send_lo = the first `depth` owned planes, send_hi =
  * the last `depth`, recv_lo / recv_hi = the `depth` ghost planes next to the slab; bytes = depth *
- * plane_bytes, each range contiguous.  Depth 2 serves cfd_sweep_pair_and_filter.  No counterpart in the
- * reference (single address space). */
+ * plane_bytes, each range contiguous.  Depth 2 serves cfd_sweep_pair_and_filter, depth 3 the one-pass step
+ * (cfd_step_one_pass*).  No counterpart in the reference (single address space). */
 int cfd_halo_planes_depth(cfd_handle *h, int depth, void **send_lo, void **send_hi, void **recv_lo,
                           void **recv_hi, size_t *bytes);
 
@@ -242,6 +243,29 @@ int cfd_set_ghost_active(cfd_handle *h, const uint8_t *lo_plane, const uint8_t *
 
 /* *available = 1 if cfd_sweep_pair_and_filter runs as one pass for this handle as it is now. */
 int cfd_pair_available(cfd_handle *h, int *available);
+
+/* The same masks two planes deep (depth = 1 or 2): lo_planes = the lower neighbour's last `depth` planes,
+ * hi_planes = the upper neighbour's first `depth` planes, each in ascending x, depth*ny*nz bytes.  Depth 2 serves
+ * the one-pass step of a slab (cfd_step_one_pass*): the once-swept values of the second ghost plane and the
+ * twice-swept values of the first depend on those cells' `active` flags. */
+int cfd_set_ghost_active_depth(cfd_handle *h, int depth, const uint8_t *lo_planes, const uint8_t *hi_planes);
+
+/* runSingleStep (src/Main.hs:192-200) as ONE pass over memory: the three sweeps of the step and the live
+ * correctPrevTime in one launch, the two intermediate fields held on chip (2-D grids with CFD_FLAG_FAST_MATH;
+ * cfd_one_pass_step_available tells whether it can run for the handle as it is now).  cfd_step takes this form
+ * by itself on an undecomposed grid; these entry points exist for slabs, which cfd_step refuses:
+ *   - the step reads THREE ghost planes of the current slot on every side that has a neighbour
+ *     (cfd_halo_planes_depth with depth 3: ONE exchange per step) and needs the neighbours' masks two planes
+ *     deep (cfd_set_ghost_active_depth, once);
+ *   - cfd_step_one_pass runs the whole step on the handle's stream; cfd_step_one_pass_begin launches the blocks
+ *     whose stencils stay inside the owned planes, so that the exchange can run beside them on another stream,
+ *     and cfd_step_one_pass_end_on launches the rest on `stream` (ordered by the caller after the arrival of the
+ *     ghost planes; later work is ordered after `stream` AND the handle's stream) and completes the step.
+ * Results are identical, bit for bit, to cfd_sweep x3 + cfd_time_filter with an exchange before every sweep. */
+int cfd_one_pass_step_available(cfd_handle *h, int *available);
+int cfd_step_one_pass(cfd_handle *h);
+int cfd_step_one_pass_begin(cfd_handle *h);
+int cfd_step_one_pass_end_on(cfd_handle *h, void *stream);
 
 /* The HIP stream (hipStream_t) all of the handle's kernels run on. */
 int cfd_stream(cfd_handle *h, void **stream);
@@ -269,7 +293,8 @@ int cfd_sweep_timing(cfd_handle *h, double *total_ms, int64_t *launches, int res
 
 /* As cfd_sweep_timing, per kernel kind: 0 = plain sweep launches, 1 = sweeps fused with the time
  * filter (the last sweep of a step once currAbsTime > 1), 2 = launches that do the second and third
- * sweep of a step and the filter in one pass (cfd_sweep_pair_and_filter where it applies). */
+ * sweep of a step and the filter in one pass (cfd_sweep_pair_and_filter where it applies), 3 = launches
+ * that do a whole step -- three sweeps and the filter -- in one pass (cfd_step, cfd_step_one_pass*). */
 int cfd_kernel_timing(cfd_handle *h, int kind, double *total_ms, int64_t *launches, int reset);
 
 /* Number of live fields the device holds per slot: 5 when nz == 1 and W is identically
@@ -314,9 +339,11 @@ int cfd_multi_create_rank(const cfd_params *p, int rank, int world, const void *
 void cfd_multi_destroy(cfd_multi *m);
 
 /* runSingleStep (src/Main.hs:192-200) nsteps times on every slab: per step three sweeps with a one-plane
- * exchange before each, or -- where every slab can run cfd_sweep_pair_and_filter -- one sweep, a two-plane
+ * exchange before each; or -- where every slab can run cfd_sweep_pair_and_filter -- one sweep, a two-plane
  * exchange and the one-pass tail, both exchanges queued on a side stream beside the first sweep's interior
- * planes.  Asynchronous: returns when the work is queued. */
+ * planes; or -- where every slab can run cfd_step_one_pass -- ONE three-plane exchange on the side stream beside
+ * the blocks of the one-pass step that read owned planes only, then the blocks next to the neighbours.
+ * Asynchronous: returns when the work is queued. */
 int cfd_multi_step(cfd_multi *m, int nsteps);
 
 /* totalDensity (src/Main.hs:269-270) over all slabs.  RCCL: per-slab sums on the device and one ncclAllReduce
@@ -332,8 +359,10 @@ int cfd_multi_time(cfd_multi *m, int *curr_mod_time, int *curr_abs_time);
 /* Blocks until everything queued by the handle has finished on every device. */
 int cfd_multi_sync(cfd_multi *m);
 
-/* How the handle runs: slabs held by this process, whether a step's tail is the one-pass form, whether its
- * exchanges run on the side stream beside the interior planes. */
+/* How the handle runs: slabs held by this process; *one_pass_tail = 2 if every slab runs the whole step as one
+ * pass (one three-plane exchange per step), 1 if the step's tail (second and third sweep) is one pass (two
+ * exchanges per step), 0 for three sweeps with an exchange before each; whether the exchanges run on the side
+ * stream beside the interior planes. */
 int cfd_multi_info(cfd_multi *m, int *local_slabs, int *one_pass_tail, int *overlapped);
 
 /* Local slab i: its single-slab handle (for cfd_set_timing / cfd_kernel_timing / cfd_property_slice; do not

@@ -34,20 +34,32 @@ def _assert_same(m, g, what):
                                            (4, (9, 20, 1), FAST), (3, (7, 50, 1), FAST), (2, (40, 33, 1), 0),
                                            (3, (11, 6, 5), FAST), (4, (21, 18, 19), FAST), (2, (9, 8, 7), 0)])
 @pytest.mark.parametrize("overlap", ["1", "0"])
-def test_virtual_slabs_behind_the_c_abi_match_the_undecomposed_run(n, shape, flags, overlap, monkeypatch):
+@pytest.mark.parametrize("trio,trio_chunk", [("1", None), ("1", 2), ("1", 5), ("0", None)])
+def test_virtual_slabs_behind_the_c_abi_match_the_undecomposed_run(n, shape, flags, overlap, trio, trio_chunk, monkeypatch):
+    """trio: the slabs run the whole step as one pass (one three-plane exchange per step; chunk lengths that make
+    every block, some blocks or no block of a slab touch a ghost plane) or the plain sweep + the one-pass tail
+    (two exchanges per step); where a slab has too few planes, or in 3-D / strict, three sweeps with an exchange each."""
+    if trio_chunk is not None and not (flags == FAST and shape[2] == 1):
+        pytest.skip("the chunk length of the one-pass step only matters where that step runs")
     monkeypatch.setenv("CFD_MULTI_OVERLAP", overlap)
+    monkeypatch.setenv("CFD_MULTI_TRIO", trio)
+    if trio_chunk is not None:
+        monkeypatch.setenv("CFD_TRIO_CHUNK", str(trio_chunk))
     params, fields, active = small_case(shape[0], shape[1], shape[2], 61)
-    # inactive cells on the planes next to a slab boundary: the once-swept ghost values depend on their masks
+    # inactive cells on the planes next to a slab boundary: the once- and twice-swept ghost values depend on their masks
     act = np.array(active).reshape(shape)
     act[shape[0] // n, ::3, :] = 0
     act[max(shape[0] // n - 1, 0), 1::4, :] = 0
+    act[max(shape[0] // n - 2, 0), 2::5, :] = 0
+    act[min(shape[0] // n + 1, shape[0] - 1), 3::4, :] = 0
     active = act.reshape(-1)
     g = _single(params, fields, active, flags)
     m = _multi(params, fields, active, flags, n)
     local, one_pass, overlapped = m.info()
     assert local == n
-    if flags == FAST and shape[2] == 1 and min((shape[0] * (i + 1)) // n - (shape[0] * i) // n for i in range(n)) >= 2:
-        assert one_pass and overlapped == (overlap == "1")
+    fewest = min((shape[0] * (i + 1)) // n - (shape[0] * i) // n for i in range(n))
+    if flags == FAST and shape[2] == 1 and fewest >= 2:
+        assert one_pass == (2 if (trio == "1" and fewest >= 3) else 1) and overlapped == (overlap == "1")
     for step in range(3):
         g.step(1)
         m.step(1)
@@ -55,6 +67,29 @@ def test_virtual_slabs_behind_the_c_abi_match_the_undecomposed_run(n, shape, fla
     g.step(2)
     m.step(2)
     _assert_same(m, g, "two more steps")
+    if one_pass == 2:       # and the launches really were the one-pass step
+        sl = m.slab(0)
+        sl.set_timing(True)
+        m.step(1); m.sync()
+        assert sl.kernel_timing(3)[1] >= 1 and sl.kernel_timing(0)[1] == 0 and sl.kernel_timing(2)[1] == 0
+
+
+@pytest.mark.parametrize("n,shape", [(2, (64, 70)), (3, (50, 300)), (3, (9, 40))])
+@pytest.mark.parametrize("flags", [FAST, 0])
+@pytest.mark.parametrize("trio", ["1", "0"])
+def test_cavity_cut_into_slabs_matches_the_undecomposed_run(n, shape, flags, trio, monkeypatch):
+    """The lid-driven-cavity configuration (U = V = 0 exactly in the interior, so the unknown's coefficient takes
+    its other branch in every cell; an inactive ring of walls) through the library's slab driver: ghost planes two
+    and three deep, the neighbours' masks, against the undecomposed run, bit for bit, strict and re-associated."""
+    from cfd_amd import cases
+    monkeypatch.setenv("CFD_MULTI_TRIO", trio)
+    params, fields, active = cases.cavity_2d(shape[0], shape[1])
+    g = _single(params, fields, active, flags)
+    m = _multi(params, fields, active, flags, n)
+    for step in range(4):
+        g.step(1)
+        m.step(1)
+        _assert_same(m, g, "cavity step %d" % step)
 
 
 def test_one_slab_is_the_plain_library():

@@ -448,8 +448,30 @@ def test_slab_pair_needs_masks_and_two_planes():
         g.set_ghost_active(None, None)                  # a mask is needed on the side that has a neighbour
     g.set_ghost_active(np.ones(9, np.uint8), None)
     assert g.pair_available()
+    # the one-pass step needs the masks two planes deep
+    assert not g.one_pass_step_available()
     with pytest.raises(CfdError):
-        g.halo_planes(3)
+        g.step_one_pass()
+    with pytest.raises(CfdError):
+        g.step_one_pass_begin()
+    g.set_ghost_active(np.ones(18, np.uint8), None, depth=2)
+    assert g.one_pass_step_available() and g.pair_available()
+    g.halo_planes(3)
+    with pytest.raises(CfdError):
+        g.halo_planes(4)
+    with pytest.raises(CfdError):
+        g.set_ghost_active(np.ones(27, np.uint8), None, depth=3)
+    g.step_one_pass_begin()
+    with pytest.raises(CfdError):
+        g.sweep_end()                                   # the open call is a step, not a sweep
+    with pytest.raises(CfdError):
+        g.sweep(True)
+    g.step_one_pass_end()
+    assert (g.currModTime, g.currAbsTime) == (1, 1)
+    two = [f[:18] for f in fields]
+    g2 = AdjGraph(dict(p, nx=2), two, active[:18])
+    g2.set_ghost_active(np.ones(18, np.uint8), None, depth=2)
+    assert g2.pair_available() and not g2.one_pass_step_available()      # three planes are sent: they must be its own
     one = [f[:9] for f in fields]
     p1 = dict(p)
     p1["nx"] = 1
