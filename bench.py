@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--virtual-slabs", type=int, default=1,
                     help="N = 1 only: cut this GPU's grid into K slabs driven by the library (copy transport), to "
                          "measure what the decomposition itself costs")
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="N > 1: skip the bit-for-bit check of the decomposition against an undecomposed run before timing")
+    ap.add_argument("--preflight-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the rendezvous and the pre-flight may take before the rank exits with status 3")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse launch + rendezvous + reduction without a GPU (gloo, no compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,6 +205,21 @@ def dry_run(a, world, rank):
         dist.destroy_process_group()
 
 
+def start_watchdog(seconds, what, rank):
+    """A timer thread that ends THIS process (exit status 3, no re-exec) if `what` has not finished in time: a rank
+    stuck in a rendezvous or in a collective whose peer never arrives must fail the job, not hang it."""
+    import threading
+
+    def fire():
+        sys.stderr.write("rank %d: %s did not finish within %.0f s; exiting with status 3\n" % (rank, what, seconds))
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def sclk_reader(device_index):
     """Returns a function that reads the GPU's current shader clock in MHz from sysfs (None where unreadable)."""
     import glob
@@ -240,8 +259,11 @@ def main():
     from cfd_amd import cases
     from cfd_amd.slab import SlabGraph, init_rccl
     c_driver = a.slab_driver == "c" and (world > 1 or a.virtual_slabs > 1)
+    watchdog = start_watchdog(a.preflight_timeout, "rendezvous + pre-flight", rank) if world > 1 else None
     if world > 1 and c_driver:
-        dist.init_process_group("gloo")                 # control plane only; the halo planes go through the library's RCCL
+        import datetime
+        # control plane only; the halo planes go through the library's RCCL
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
     elif world > 1:
         init_rccl(torch.device("cuda", local_rank))     # rank, world size and rendezvous from the environment
     red_dev = "cpu" if (world > 1 and c_driver) else "cuda"
@@ -253,6 +275,60 @@ def main():
             raise SystemExit("--strong: fewer x-planes than ranks")
         a.nx = global_nx // world + (1 if rank < global_nx % world else 0)
     two_d = a.nz == 1
+    run_flags = a.flags | (4 if a.arith == "fast" else 0)
+
+    def all_agree(ok):
+        """True if `ok` holds on every rank (a collective on the current default group)."""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def library_slab(params, fields, active):
+        """This rank's slab behind cfd_multi_create_rank (a collective: rank 0 makes the communicator id)."""
+        from cfd_amd.multi import MultiGraph, comm_unique_id
+        box = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return MultiGraph.for_rank(params, fields, active, rank, world, box[0])
+
+    def preflight_of(make):
+        """Runs the pre-flight with slabs made by `make`; every rank gets the same verdict."""
+        from cfd_amd import preflight
+        rep, err = None, None
+        try:
+            rep = preflight.run(rank, world, run_flags, a.nz, lambda name, p, f, m, x0, x1: make(p, f, m), device=local_rank)
+        except Exception as e:                  # e.g. the communicator could not be created on this rank
+            err = "%s: %s" % (type(e).__name__, e)
+        ok = all_agree(rep is not None and rep["ok"])
+        if rep is None:
+            rep = {"ok": False, "cases": [], "steps": 0, "detail": "rank %d: %s" % (rank, err)}
+        if not ok and rep["ok"]:
+            rep = dict(rep, ok=False, detail="another rank reported a difference")
+        if rep["detail"]:
+            sys.stderr.write("pre-flight, rank %d: %s\n" % (rank, rep["detail"]))
+        return rep
+
+    fallback, preflight_report = None, None
+    if world > 1 and not a.no_preflight:
+        if c_driver:
+            preflight_report = dict(preflight_of(library_slab), driver="library (cfd_multi_*, RCCL)")
+            if not preflight_report["ok"]:
+                # one failure sends every rank to the torch.distributed driver, on a rendezvous port of its own
+                fallback = "pre-flight of the library's slab driver failed: %s" % preflight_report["detail"]
+                dist.destroy_process_group()
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                init_rccl(torch.device("cuda", local_rank))
+                c_driver, red_dev = False, "cuda"
+        if not c_driver:
+            first = preflight_report
+            preflight_report = dict(preflight_of(lambda p, f, m: SlabGraph(p, f, m, rank=rank, world=world)),
+                                    driver="cfd_amd.slab over torch.distributed (nccl backend)")
+            if first is not None:
+                preflight_report["library_driver"] = first
+            if not preflight_report["ok"]:
+                sys.stderr.write("rank %d: the decomposed run does not reproduce the undecomposed one; not timing it\n" % rank)
+                sys.stderr.flush()
+                os._exit(4)
+
     if two_d and a.case == "cavity":
         first = sum(global_nx // world + (1 if r < global_nx % world else 0) for r in range(rank)) if a.strong \
             else a.nx * rank
@@ -263,18 +339,16 @@ def main():
         params, fields, active = cases.synthetic_3d(a.nx, a.ny, a.nz, seed=3 + rank)
     params["device"] = local_rank
     params["dt"] = a.dt
-    params["flags"] = a.flags | (4 if a.arith == "fast" else 0)
+    params["flags"] = run_flags
     if c_driver:
-        from cfd_amd.multi import MultiGraph, comm_unique_id
+        from cfd_amd.multi import MultiGraph
 
         class LibrarySlabs:
             """The slabs of this process behind cfd_multi_*, with the few verbs the loop below uses."""
 
             def __init__(self):
                 if world > 1:
-                    box = [comm_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(box, src=0)
-                    self.m = MultiGraph.for_rank(params, fields, active, rank, world, box[0])
+                    self.m = library_slab(params, fields, active)
                 else:
                     self.m = MultiGraph(params, fields, active, a.virtual_slabs, devices=[local_rank] * a.virtual_slabs)
                 self.graph = self.m.slab(0)
@@ -291,31 +365,31 @@ def main():
             def close(self):
                 self.m.close()
 
-        g, fallback = None, None
+        g, err = None, None
         try:
             g = LibrarySlabs()
         except Exception as e:          # e.g. the library's RCCL communicator could not be created
             if world == 1:
                 raise
-            fallback = "%s: %s" % (type(e).__name__, e)
-        if world > 1:
+            err = "%s: %s" % (type(e).__name__, e)
+        if world > 1 and not all_agree(err is None):
             # every rank must take the same path: one failure sends all of them to the torch.distributed driver
-            ok = torch.tensor([0 if fallback else 1], dtype=torch.int64)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if not int(ok.item()):
-                if g is not None:
-                    g.close()
-                    g = None
-                sys.stderr.write("rank %d: library slab driver unavailable (%s); using cfd_amd.slab over "
-                                 "torch.distributed\n" % (rank, fallback or "another rank failed"))
-                fallback = fallback or "another rank could not create its slab"
-                dist.destroy_process_group()
-                init_rccl(torch.device("cuda", local_rank))
-                c_driver, red_dev = False, "cuda"
+            if g is not None:
+                g.close()
+                g = None
+            sys.stderr.write("rank %d: library slab driver unavailable (%s); using cfd_amd.slab over "
+                             "torch.distributed\n" % (rank, err or "another rank failed"))
+            fallback = err or "another rank could not create its slab"
+            dist.destroy_process_group()
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            init_rccl(torch.device("cuda", local_rank))
+            c_driver, red_dev = False, "cuda"
     else:
-        g, fallback = None, None
+        g = None
     if g is None:
         g = SlabGraph(params, fields, active, rank=rank, world=world)
+    if watchdog is not None:
+        watchdog.cancel()
 
     def barrier():
         if world > 1:
@@ -456,6 +530,7 @@ def main():
                        (", driven by the library (cfd_multi_*: %s)" % ("RCCL" if world > 1 else "device copies"))
                        if c_driver else (", driven by cfd_amd.slab over torch.distributed" if world > 1 else "")),
                    "kernel": kernel_name, "arithmetic": a.arith, "dt": a.dt,
+                   "preflight": preflight_report if world > 1 else "not applicable at N = 1 (no decomposition)",
                    "fields_finite_at_end": bool(final_density == final_density and abs(final_density) != float("inf"))},
         # the launch kind that takes most of the timed region; every kind is listed under "kernels"
         "roofline": {"bound": "hbm", "achieved": dominant["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -2434,8 +2434,26 @@ void cfd_destroy(cfd_handle* h) {
     delete h;
 }
 
+// For the library's other translation unit (cfd_multi.hip): cfd_create on a stream the caller owns, so that a slab
+// never creates a stream of its own only to destroy it again (a process that keeps creating and destroying streams
+// hands hardware queues on between them).
+static int create_impl(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
+                       bool own_stream, hipStream_t stream, cfd_handle** out);
+
+int cfd_internal_create_on(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
+                           void* stream, cfd_handle** out) {
+    return create_impl(p, fields, active, false, (hipStream_t)stream, out);
+}
+
 int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
                cfd_handle** out) {
+    return create_impl(p, fields, active, true, nullptr, out);
+}
+
+}  // extern "C"
+
+static int create_impl(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
+                       bool own_stream, hipStream_t stream, cfd_handle** out) {
     if (!p || !fields || !active || !out) return fail(CFD_E_ARG, "cfd_create: null pointer");
     *out = nullptr;
     if (p->nx < 1 || p->ny < 1 || p->nz < 1) return fail(CFD_E_ARG, "cfd_create: grid extents must be >= 1");
@@ -2500,7 +2518,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     if (const char* e = getenv("CFD_VARIANT")) h->variant = atoi(e);
     for (int i = 0; i < 4; ++i) { h->buf[i] = nullptr; h->map[i] = i; }
     h->ghost_mask_depth = 0;
-    h->d_active = nullptr; h->d_partial = nullptr; h->stream = nullptr; h->own_stream = true;
+    h->d_active = nullptr; h->d_partial = nullptr; h->stream = stream; h->own_stream = own_stream;
     h->timing = false;
     for (int kd = 0; kd < NKIND; ++kd) { h->t_ms[kd] = 0.0; h->t_launches[kd] = 0; }
     h->mew.assign(fields[5], fields[5] + n);
@@ -2516,7 +2534,7 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
     } while (0)
 
     if (int rc = scratch_setup(dev)) { cfd_destroy(h); return rc; }
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (own_stream) CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) {
         CREATE_TRY(hipMalloc((void**)&h->buf[i], h->slot_elems * sizeof(double)));
         CREATE_TRY(hipMemsetAsync(h->buf[i], 0, h->slot_elems * sizeof(double), h->stream));
@@ -2544,6 +2562,8 @@ int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const
 }
 
 static int sweep_in_place(cfd_handle* h, bool with_filter, bool* did_fuse);
+
+extern "C" {
 
 int cfd_sweep(cfd_handle* h, int step_time) {
     if (!h) return fail(CFD_E_ARG, "cfd_sweep: null handle");

@@ -12,7 +12,7 @@
 // ncclAllReduce for the density sum) or plain copies.  A plane of all live fields is one contiguous run in a
 // time slot, so a halo is ONE message per neighbour with no pack kernel.
 //
-// Streams: per device one compute stream and one high-priority side stream, shared by every slab on that
+// Streams: per device one compute stream and one side stream (both at the default priority), shared by every slab on that
 // device (several virtual slabs on one GPU therefore never hold more than two streams).  A step with the
 // one-pass tail hides both of its exchanges behind the first sweep's interior planes:
 //     side:  wait(previous step) -> exchange 1 plane -> edge planes of sweep 1 -> exchange 2 planes -> event
@@ -30,6 +30,9 @@
 #include "../../include/cfd_hip.h"
 
 extern "C" int cfd_internal_fail(int code, const char* msg);     // cfd_hip.hip: sets cfd_last_error's text
+// cfd_hip.hip: cfd_create on a stream the caller owns (the slab launches there from the start)
+extern "C" int cfd_internal_create_on(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
+                                      void* stream, cfd_handle** out);
 
 namespace {
 
@@ -228,14 +231,11 @@ int streams_for(cfd_multi* m, int device, int* index) {
         if (m->streams[i].device == device) { *index = (int)i; return CFD_OK; }
     DeviceStreams d{device, nullptr, nullptr};
     M_HIP(hipSetDevice(device));
-    int lo = 0, hi = 0;
-    M_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));       // hi = the numerically lowest value = highest priority
+    // Both streams at the default priority, always: a step that mixes stream priorities in its cross-stream waits has
+    // stalled on ROCm 7.2 / MI355X (after streams had been created and destroyed earlier in the process); with equal
+    // priorities the same sequence of launches, copies and waits never did.
     M_HIP(hipStreamCreateWithFlags(&d.main, hipStreamNonBlocking));
-    // A high-priority side stream makes its few blocks start ahead of the interior launch, but on ROCm 7.2 / MI355X a
-    // process that has created and destroyed other streams before can then stop in the step's cross-stream waits
-    // (reproduced: scripts/exp/hang_probe3.py); with equal priorities the same sequence never did.  Off by default.
-    if (env_flag("CFD_MULTI_SIDE_PRIORITY", false)) M_HIP(hipStreamCreateWithPriority(&d.side, hipStreamNonBlocking, hi));
-    else M_HIP(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
+    M_HIP(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
     m->streams.push_back(d);
     *index = (int)m->streams.size() - 1;
     return CFD_OK;
@@ -249,9 +249,8 @@ int make_slab(cfd_multi* m, Slab& s, const double* const fields[CFD_NPROP], cons
     q.flags = m->p.flags | extra_flags;
     q.ghost_lo = s.rank > 0;
     q.ghost_hi = s.rank < m->world - 1;
-    M_CFD(cfd_create(&q, fields, active, &s.h));
     M_CFD(streams_for(m, s.device, &s.ds));
-    M_CFD(cfd_set_stream(s.h, (void*)main_of(m, s)));
+    M_CFD(cfd_internal_create_on(&q, fields, active, (void*)main_of(m, s), &s.h));
     M_HIP(hipSetDevice(s.device));
     M_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     M_HIP(hipEventCreateWithFlags(&s.edge, hipEventDisableTiming));

@@ -30,14 +30,12 @@ import numpy as np
 from .solver import AdjGraph
 
 
-def init_rccl(device, high_priority=False, **kw):
-    """Process group on the nccl (= RCCL) backend bound to `device` (a torch.device).  high_priority: the
-    group's transfers run on a stream of torch's high-priority pool.  Off by default: on this runtime a step
-    that mixes stream priorities has been seen to stall once hardware queues have been handed on between
-    streams, and this driver does not overlap its exchanges with the sweeps anyway."""
+def init_rccl(device, **kw):
+    """Process group on the nccl (= RCCL) backend bound to `device` (a torch.device).  The group's transfers run at
+    the default stream priority: on this runtime a step that mixes stream priorities has been seen to stall once
+    hardware queues have been handed on between streams."""
     import torch.distributed as dist
-    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=bool(high_priority))
-    dist.init_process_group("nccl", device_id=device, pg_options=opts, **kw)
+    dist.init_process_group("nccl", device_id=device, **kw)
 
 
 class _DeviceSpan:

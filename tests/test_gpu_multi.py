@@ -161,3 +161,45 @@ def test_compiled_host_over_three_slabs_prints_the_reference_stdout():
             assert abs(x - y) <= 1e-12 * abs(y), (a, b)
         else:
             assert a == b
+
+
+class _VirtualRank:
+    """Rank `rank` of a K-slab decomposition run entirely on this GPU by the library's slab driver (device
+    copies in place of RCCL), seen the way the pre-flight sees one rank's slab."""
+
+    def __init__(self, name, world, rank, flags, spoil=False):
+        from cfd_amd import preflight
+        params, fields, active = next((p, f, m) for n, p, f, m in preflight.grids(world, 1) if n == name)
+        self.m = _multi(dict(params, dt=1e-7), fields, active, flags, world)
+        nx, plane = params["nx"], params["ny"]
+        self.a, self.b = (nx * rank // world) * plane, (nx * (rank + 1) // world) * plane
+        self.spoil = spoil
+
+    def step(self, n):
+        self.m.step(n)
+
+    def read_fields(self, rel):
+        out = [f[self.a:self.b].copy() for f in self.m.read_fields(rel)]
+        if self.spoil and rel == 0:
+            out[4][7] = np.nextafter(out[4][7], 1e9)        # one Temperature value off by one ulp
+        return out
+
+    def total_density(self):
+        return self.m.total_density()
+
+    def close(self):
+        self.m.close()
+
+
+@pytest.mark.parametrize("flags", [FAST, 0])
+def test_preflight_of_a_decomposed_run(flags):
+    """The pre-flight bench.py runs before it times N > 1 ranks, rehearsed with three virtual ranks on this GPU: it
+    passes on the library's slab driver and names rank, grid, step, slot, property and plane when a single value of
+    a single rank is off by one ulp."""
+    from cfd_amd import preflight
+    for rank in range(3):
+        rep = preflight.run(rank, 3, flags, 1, lambda name, p, f, m, x0, x1: _VirtualRank(name, 3, rank, flags))
+        assert rep["ok"] and rep["detail"] is None and len(rep["cases"]) == 2 and rep["steps"] == 3, rep
+    rep = preflight.run(1, 3, flags, 1, lambda name, p, f, m, x0, x1: _VirtualRank(name, 3, 1, flags, spoil=True))
+    assert not rep["ok"]
+    assert "rank 1 of 3" in rep["detail"] and "Temperature differs in 1 cells" in rep["detail"] and "step 1" in rep["detail"]
