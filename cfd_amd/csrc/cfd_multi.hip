@@ -152,10 +152,28 @@ int record(cfd_multi* m, bool edge_event) {
     return CFD_OK;
 }
 
-// One sweep of every slab with its one-plane exchange on the compute stream: exchange, interior, edge.
+// One sweep of every slab with its one-plane exchange.  Overlapped: the exchange runs on the side stream beside the
+// launch of the planes that read no ghost plane (cells are independent within a sweep: applyDiffEq_adj maps over the
+// nodes of one snapshot, src/Main.hs:211); the planes next to a neighbour follow on the compute stream once the ghost
+// planes have arrived.  Otherwise everything is queued on the compute stream: exchange, interior, edge.
 int sweep_all(cfd_multi* m, int step_time, int with_filter) {
     if (m->world == 1) {
         for (Slab& s : m->slab) M_CFD(with_filter ? cfd_sweep_and_filter(s.h) : cfd_sweep(s.h, step_time));
+        return record(m, false);
+    }
+    if (m->overlap) {
+        for (Slab& s : m->slab) {
+            M_HIP(hipSetDevice(s.device));
+            M_HIP(hipStreamWaitEvent(side_of(m, s), s.done, 0));    // the slot the sweep reads is complete
+        }
+        M_CFD(exchange(m, 1, true, READY_DONE));
+        for (Slab& s : m->slab) M_CFD(cfd_sweep_begin_depth(s.h, step_time, with_filter, 1));
+        for (Slab& s : m->slab) {
+            M_HIP(hipSetDevice(s.device));
+            M_HIP(hipEventRecord(s.side_done, side_of(m, s)));
+            M_HIP(hipStreamWaitEvent(main_of(m, s), s.side_done, 0));
+        }
+        for (Slab& s : m->slab) M_CFD(cfd_sweep_end(s.h));
         return record(m, false);
     }
     M_CFD(exchange(m, 1, false, READY_DONE));
@@ -564,7 +582,7 @@ int cfd_multi_info(cfd_multi* m, int* local_slabs, int* one_pass_tail, int* over
     if (!m) return fail(CFD_E_ARG, "cfd_multi_info: null handle");
     if (local_slabs) *local_slabs = (int)m->slab.size();
     if (one_pass_tail) *one_pass_tail = m->trio ? 2 : (m->pair ? 1 : 0);
-    if (overlapped) *overlapped = (m->pair && m->overlap && m->world > 1) ? 1 : 0;
+    if (overlapped) *overlapped = (m->overlap && m->world > 1) ? 1 : 0;
     return CFD_OK;
 }
 
