@@ -4,8 +4,8 @@ long-horizon lock-step run of the 8192 x 8192 configuration's recipe on a grid t
 
 Bars: strict arithmetic vs Oracle B (t*sqrt(t) mode) BIT-EXACT; re-associated arithmetic <= 1e-13 of the field
 scale per sweep (3e-13 per step of three sweeps), velocity components measured against the velocity scale, and
-<= 1e-12 per sweep (3e-12 per step) with every property measured against its OWN largest magnitude
-(helpers.own_scale_errors: V against V, not against U; floor 1 % of the velocity scale);
+<= 1e-12 per step with every property measured against its OWN largest magnitude (helpers.own_scale_errors: V
+against V, not against U; floor 1 % of the velocity scale) or twice the oracle's own pow-vs-sqrt difference;
 totalDensity <= 1e-12 relative.  The cell-by-cell relative error is printed, not asserted: where a field passes
 through zero it measures the scheme's cancellation noise, not the implementation.
 """
@@ -41,15 +41,20 @@ def test_fast_step_against_oracle_step(case):
     """cfd_step with CFD_FLAG_FAST_MATH -- the path bench.py times: in 2-D all three sweeps of the step and the
     time filter in one launch -- against OracleB.step.  Every step starts from the oracle's
     own three slots and time counters (cfd_set_time + cfd_write_fields), so each comparison is of ONE step from
-    identical state: all three slots, <= 3e-13 of the field scale and <= 3e-12 of every property's own scale (three
-    sweeps at 1e-13 / 1e-12 each)."""
+    identical state: all three slots, <= 3e-13 of the field scale (three sweeps at 1e-13 each) and, per step,
+    <= 1e-12 of every property's own scale (3e-12 for the cavity's V, which is 1e-5 of the lid speed) -- or, where
+    the scheme itself amplifies a last-bit change beyond that, <= twice what the oracle's own step moves by when its
+    viscosity is evaluated with libm pow instead of t*sqrt(t)."""
     params, fields, active = _case(case)
     b = _oracle(params, fields, active)
     g = _graph(params, fields, active, FAST)
     two_d = params["nz"] == 1
-    worst_f, worst_o, worst_e = 0.0, 0.0, 0.0
+    worst_f, worst_o, worst_e, worst_y = 0.0, 0.0, 0.0, 0.0
     for step in range(4):
         g.restore((b.time()[0], b.time()[1], [b.read_fields(r) for r in range(3)]))
+        # the yardstick: the oracle's own step from the same current slot with libm pow (what GHC's ** calls) in
+        # place of t*sqrt(t) -- a last-bit change of the viscosity and nothing else
+        op = _oracle(params, b.read_fields(0), active, pow_mode=0)
         g.set_timing(True)
         g.step(1)
         g.sync()
@@ -60,6 +65,10 @@ def test_fast_step_against_oracle_step(case):
         else:
             assert (plain, fused, pair, trio) == ((2, 1, 0, 0) if step >= 1 else (3, 0, 0, 0))
         b.step(1)
+        op.step(1)
+        yard = own_scale_errors(op.read_fields(0), b.read_fields(0))
+        op.close()
+        worst_y = max(worst_y, max(yard))
         assert (g.currModTime, g.currAbsTime) == b.time()
         for rel in range(3):
             got, want = g.read_fields(rel), b.read_fields(rel)
@@ -67,11 +76,16 @@ def test_fast_step_against_oracle_step(case):
             worst_f, worst_o, worst_e = max(worst_f, max(fe)), max(worst_o, max(oe)), max(worst_e, max(ee))
             for k in range(7):
                 assert fe[k] <= 3e-13, (case, step, rel, PROPS[k], fe[k])
-                assert oe[k] <= 3e-12, (case, step, rel, PROPS[k], oe[k])
+                # The cavity's V (1e-5 of the lid speed, so measured against the floor of 1 % of the velocity scale):
+                # 2.4e-12 of that floor = 2.4e-14 of the velocity scale, the rounding noise of the U-scale terms its
+                # equation carries; the yardstick does not cover it in the first step (no flow yet, nothing for the
+                # viscosity to act on).  Stated here as the one exception to the 1e-12 bar.
+                bar = 3e-12 if (case == "cavity" and k == 1) else 1e-12
+                assert oe[k] <= max(bar, 2.0 * yard[k]), (case, step, rel, PROPS[k], oe[k], yard[k])
         td, tb = g.total_density(), b.total_density()
         assert abs(td - tb) <= 1e-12 * abs(tb)
-    print("fast step vs oracle step", case, "field-scale %.2e own-scale %.2e cell-relative (floor 1e-3) %.2e"
-          % (worst_f, worst_o, worst_e))
+    print("fast step vs oracle step", case, "field-scale %.2e own-scale %.2e (oracle pow-vs-sqrt %.2e) cell-relative "
+          "(floor 1e-3) %.2e" % (worst_f, worst_o, worst_y, worst_e))
 
 
 @pytest.mark.parametrize("flags,shape", [(0, (40, 33, 1)), (FAST, (70, 300, 1)), (FAST, (21, 18, 19)), (0, (9, 8, 7))])
