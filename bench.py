@@ -177,10 +177,11 @@ def one_step_fast_vs_strict(params, fields, active, flags):
 
 
 def kernel_source_hash():
-    """SHA-256 of the kernel sources: counter records are valid for the build they were taken on only."""
+    """SHA-256 of the kernel sources and their build options: counter records are valid for the build they were taken
+    on only."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("cfd_hip.hip", "sweep_math.h"):
+    for name in ("cfd_hip.hip", "sweep_math.h", "cfd_strict2d_lean.hip", "cfd_multi.hip", "Makefile"):
         with open(os.path.join(ROOT, "cfd_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

@@ -91,6 +91,7 @@ struct cfd_handle {
     int pair_chunk;         // x-planes per block of that kernel (env CFD_PAIR_CHUNK)
     bool trio_enabled;      // cfd_step runs all three sweeps of a step in one pass (env CFD_TRIO, default on)
     int trio_chunk;         // x-planes per block of that kernel (env CFD_TRIO_CHUNK)
+    int trio_first;         // x-planes of its first chunk (a slab's chunks next to a neighbour are shorter: see trio_plan)
     int trio_nts;           // its threads per sweep stage: 256 (one block per compute unit) or 128 (two)
     // a sweep split into cfd_sweep_begin / cfd_sweep_end
     struct {
@@ -1396,7 +1397,7 @@ __device__ __forceinline__ void trio_stage(const FastConsts& K, const double* __
 template <int NTS, int MINW, bool FILTER>
 __global__ void __launch_bounds__(3 * NTS, MINW)
 sweep2d_trio(FastConsts K, const double* __restrict__ src, double* __restrict__ dst, const uint8_t* __restrict__ active,
-             int nx, int ny, int lo0, int hi0, int ch, int by0, int wmax, const double* __restrict__ fpp,
+             int nx, int ny, int lo0, int hi0, int ch, int x_first, int by0, int wmax, const double* __restrict__ fpp,
              double* __restrict__ fprev) {
     extern __shared__ double smem[];
     const int t = threadIdx.x;
@@ -1409,8 +1410,9 @@ sweep2d_trio(FastConsts K, const double* __restrict__ src, double* __restrict__ 
     const int ytile = trio_tile_start(tp, bx);
     const int yend = bx + 1 < tp.ntile ? trio_tile_start(tp, bx + 1) : ny;
     const int nv = (yend < ny ? yend : ny) - ytile;
-    const int xs = by * ch;
-    const int xe = xs + ch < nx ? xs + ch : nx;
+    // chunk 0 holds x_first planes, the others ch (the last one what is left)
+    const int xs = by == 0 ? 0 : x_first + (by - 1) * ch;
+    const int xe = by == 0 ? (x_first < nx ? x_first : nx) : (xs + ch < nx ? xs + ch : nx);
     if (stage == 0)
         trio_stage<0, NTS, FILTER>(K, src, dst, active, nx, ny, lo0, hi0, xs, xe, ytile, nv, tl, wave0, fpp, fprev, smem);
     else if (stage == 1)
@@ -2063,6 +2065,42 @@ static int trio_chunk_for(int nx, int ny, int nts, int cus) {
     return best;
 }
 
+// Number of chunks of the three-sweeps kernel and the planes [xs, xe) of chunk c.
+static int trio_nchunk(const cfd_handle* h) {
+    const int nx = h->p.nx;
+    return nx <= h->trio_first ? 1 : 1 + (nx - h->trio_first + h->trio_chunk - 1) / h->trio_chunk;
+}
+static void trio_span(const cfd_handle* h, int c, int* xs, int* xe) {
+    const int nx = h->p.nx, ch = h->trio_chunk, f = h->trio_first;
+    *xs = c == 0 ? 0 : f + (c - 1) * ch;
+    *xe = c == 0 ? (f < nx ? f : nx) : (*xs + ch < nx ? *xs + ch : nx);
+}
+
+// Chunk lengths of the three-sweeps kernel for this handle.  Undecomposed: uniform (trio_chunk_for).  A slab launches
+// the chunks next to a neighbour only once the neighbour's planes have arrived, i.e. later than the others by the
+// duration of the exchange, and all blocks of a step should end together: those chunks get `margin` planes fewer
+// (env CFD_TRIO_EDGE_MARGIN, default 24 = about 60 us of the kernel's 2.4 us per plane), the others share the rest.
+static void trio_plan(cfd_handle* h) {
+    const cfd_params& p = h->p;
+    const int ch0 = trio_chunk_for(p.nx, p.ny, h->trio_nts, h->cus);
+    h->trio_chunk = h->trio_first = ch0;
+    const int edges = (p.ghost_lo ? 1 : 0) + (p.ghost_hi ? 1 : 0), nchunk = (p.nx + ch0 - 1) / ch0;
+    int margin = getenv("CFD_TRIO_EDGE_MARGIN") ? atoi(getenv("CFD_TRIO_EDGE_MARGIN")) : 24;
+    if (margin > ch0 / 4) margin = ch0 / 4;
+    if (!edges || nchunk < 3 || margin < 1) return;
+    // edges * (ch - margin) + (nchunk - edges) * ch >= nx, with the last chunk (what is left) no longer than ch - margin
+    // where it is next to a neighbour
+    int ch = (p.nx + edges * margin + nchunk - 1) / nchunk;
+    const int first = p.ghost_lo ? ch - margin : ch;
+    if (p.ghost_hi) {
+        // grow ch until the last chunk is short enough
+        while (p.nx - first - (nchunk - 2) * ch > ch - margin) ++ch;
+    }
+    if (first < 3 || p.nx - first - (nchunk - 2) * ch < 1) return;     // keep the uniform plan
+    h->trio_chunk = ch;
+    h->trio_first = p.ghost_lo ? ch - margin : ch;
+}
+
 // The strict 2-D sweep without the filter, LEAN form, instantiated in cfd_strict2d_lean.hip (compiled with the
 // minimum-register scheduling strategy, under which it fits 256 registers: two waves per SIMD).
 extern "C" int cfd_internal_launch_strict2d_lean(const SweepConsts* K, const double* src, double* dst,
@@ -2345,7 +2383,7 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
     const uint8_t* act = h->d_active + GHOST * h->plane;
     const int ch = h->trio_chunk, nts = h->trio_nts, wmax = nts - 16;
     const TrioTiles tp = trio_tiles(p.ny, wmax);
-    const int nchunk = (p.nx + ch - 1) / ch;
+    const int nchunk = trio_nchunk(h);
     if (c1 < 0) c1 = nchunk;
     if (c1 <= c0) return CFD_OK;        // empty range: nothing launched
     const size_t lds = (size_t)TRIO_LDS_ROWS * nts * sizeof(double);
@@ -2360,7 +2398,7 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
             attr_set[h->device & 63] = true;                                                       \
         }                                                                                          \
         hipExtLaunchKernelGGL(kern, dim3(tp.ntile * (c1 - c0)), dim3(3 * NTS), lds, h->stream, ea, eb, 0, h->KF,    \
-                              src, dst, act, p.nx, p.ny, lo0, hi0, ch, c0, wmax, fpp, fprev);      \
+                              src, dst, act, p.nx, p.ny, lo0, hi0, ch, h->trio_first, c0, wmax, fpp, fprev); \
     } while (0)
     if (nts == 128) { if (fpp) LAUNCH_TRIO(128, 3, true); else LAUNCH_TRIO(128, 3, false); }
     else { if (fpp) LAUNCH_TRIO(256, 3, true); else LAUNCH_TRIO(256, 3, false); }
@@ -2508,8 +2546,13 @@ static int create_impl(const cfd_params* p, const double* const fields[CFD_NPROP
     if (h->pair_chunk < 1) h->pair_chunk = 1;
     h->trio_enabled = h->pair_enabled && (getenv("CFD_TRIO") ? atoi(getenv("CFD_TRIO")) != 0 : true);
     h->trio_nts = getenv("CFD_TRIO_NTS") && atoi(getenv("CFD_TRIO_NTS")) == 128 ? 128 : 256;
-    h->trio_chunk = getenv("CFD_TRIO_CHUNK") ? atoi(getenv("CFD_TRIO_CHUNK")) : trio_chunk_for(p->nx, p->ny, h->trio_nts, h->cus);
-    if (h->trio_chunk < 1) h->trio_chunk = 1;
+    if (getenv("CFD_TRIO_CHUNK")) {
+        h->trio_chunk = atoi(getenv("CFD_TRIO_CHUNK"));
+        if (h->trio_chunk < 1) h->trio_chunk = 1;
+        h->trio_first = h->trio_chunk;
+    } else {
+        trio_plan(h);
+    }
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
     h->chunk_auto = true;
@@ -2946,12 +2989,12 @@ int cfd_step_one_pass(cfd_handle* h) {
 
 // Chunks of the one-pass step whose blocks read owned planes only: a block of planes [xs, xe) reads planes xs - 3 .. xe + 2.
 static void trio_interior_chunks(const cfd_handle* h, int* c0, int* c1) {
-    const int ch = h->trio_chunk, nx = h->p.nx, nchunk = (nx + ch - 1) / ch;
-    int a = 0, b = nchunk;
-    if (h->p.ghost_lo) a = (3 + ch - 1) / ch;                   // first chunk with xs >= 3
-    if (h->p.ghost_hi) while (b > a && ((b * ch < nx ? b * ch : nx) + 2 > nx - 1)) --b;    // chunks with xe + 2 <= nx - 1
-    if (a > nchunk) a = nchunk;
-    if (b < a) b = a;
+    const int nx = h->p.nx, nchunk = trio_nchunk(h);
+    int a = 0, b = nchunk, xs, xe;
+    if (h->p.ghost_lo)
+        for (; a < nchunk; ++a) { trio_span(h, a, &xs, &xe); if (xs >= 3) break; }
+    if (h->p.ghost_hi)
+        for (; b > a; --b) { trio_span(h, b - 1, &xs, &xe); if (xe + 2 <= nx - 1) break; }
     *c0 = a;
     *c1 = b;
 }
@@ -2975,7 +3018,7 @@ int cfd_step_one_pass_end_on(cfd_handle* h, void* stream) {
     if (!h->pend.open || !h->pend.trio) return fail(CFD_E_STATE, "cfd_step_one_pass_end_on: no split step is open");
     HIP_TRY(hipSetDevice(h->device));
     auto& q = h->pend;
-    const int nchunk = (h->p.nx + h->trio_chunk - 1) / h->trio_chunk;
+    const int nchunk = trio_nchunk(h);
     const hipStream_t own = h->stream;
     h->stream = (hipStream_t)stream;
     int rc = step_trio(h, 0, q.c0, false);

@@ -206,3 +206,19 @@ def test_preflight_of_a_decomposed_run(flags):
     rep = preflight.run(1, 3, flags, 1, lambda name, p, f, m, x0, x1: _VirtualRank(name, 3, 1, flags, spoil=True))
     assert not rep["ok"]
     assert "rank 1 of 3" in rep["detail"] and "Temperature differs in 1 cells" in rep["detail"] and "step 1" in rep["detail"]
+
+
+@pytest.mark.parametrize("n,shape,margin", [(3, (900, 200), None), (2, (700, 530), "40"), (4, (1300, 64), "1")])
+def test_slabs_whose_chunks_next_to_a_neighbour_are_shorter(n, shape, margin, monkeypatch):
+    """Slabs long enough for several chunks of the one-pass step: the chunks next to a neighbouring slab start late
+    (after the exchange) and are planned shorter than the others; the chunk lengths change nothing in the result."""
+    if margin is not None:
+        monkeypatch.setenv("CFD_TRIO_EDGE_MARGIN", margin)
+    params, fields, active = small_case(shape[0], shape[1], 1, 67)
+    g = _single(params, fields, active, FAST)
+    m = _multi(params, fields, active, FAST, n)
+    assert m.info()[1] == 2
+    for step in range(3):
+        g.step(1)
+        m.step(1)
+        _assert_same(m, g, "step %d" % step)
