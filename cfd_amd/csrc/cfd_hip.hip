@@ -87,6 +87,8 @@ struct cfd_handle {
     int cus;                // compute units of the device
     int variant;            // tiled-kernel launch shape (tuning knob)
     bool march3_ok;         // a 3-D x-plane fits 32-bit byte offsets (tiled 3-D kernel usable)
+    bool march3_strict_ok;  // ... and the strict tiled 3-D kernel's LDS tile fits a workgroup on this device
+    int lds_max;            // LDS bytes a workgroup may use on this device
     bool pair_enabled;      // cfd_step runs its second and third sweep in one pass (env CFD_PAIR, default on)
     int pair_chunk;         // x-planes per block of that kernel (env CFD_PAIR_CHUNK)
     bool trio_enabled;      // cfd_step runs all three sweeps of a step in one pass (env CFD_TRIO, default on)
@@ -2211,7 +2213,7 @@ static int launch_sweep(cfd_handle* h, const double* src, double* dst, const dou
 #undef LAUNCH_MARCH2W
 #undef LAUNCH_STREAM
 #undef LAUNCH_STREAM_RD
-    } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok) {
+    } else if ((p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && !h->march3_strict_ok && h->variant < 0)) {
         dim3 block(64), grid((unsigned)((h->plane + 63) / 64), x1 - x0);
         if (fast)
             hipExtLaunchKernelGGL(sweep3d_simple<MathFast3>, grid, block, 0, h->stream, ea, eb, 0, h->KF, src, dst,
@@ -2527,6 +2529,11 @@ static int create_impl(const cfd_params* p, const double* const fields[CFD_NPROP
     h->march3_ok = (double)NF3 * (double)h->plane * 8.0 < 4.0e9;
     h->cus = 256;
     if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->cus < 1) h->cus = 256;
+    // kernels with large LDS tiles run only where a workgroup may have that much (160 KiB on gfx950); elsewhere the
+    // handle falls back to the forms that need little: the per-cell strict 3-D kernel, the two-sweeps 2-D kernel
+    if (hipDeviceGetAttribute(&h->lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) != hipSuccess || h->lds_max < 1)
+        h->lds_max = 64 * 1024;
+    h->march3_strict_ok = h->march3_ok && march3_lds_bytes<MathStrict3>(256) <= (size_t)h->lds_max;
     h->pair_enabled = getenv("CFD_PAIR") ? atoi(getenv("CFD_PAIR")) != 0 : true;
     if (getenv("CFD_PAIR_CHUNK")) {
         h->pair_chunk = atoi(getenv("CFD_PAIR_CHUNK"));
@@ -2546,6 +2553,7 @@ static int create_impl(const cfd_params* p, const double* const fields[CFD_NPROP
     if (h->pair_chunk < 1) h->pair_chunk = 1;
     h->trio_enabled = h->pair_enabled && (getenv("CFD_TRIO") ? atoi(getenv("CFD_TRIO")) != 0 : true);
     h->trio_nts = getenv("CFD_TRIO_NTS") && atoi(getenv("CFD_TRIO_NTS")) == 128 ? 128 : 256;
+    if ((size_t)TRIO_LDS_ROWS * h->trio_nts * sizeof(double) > (size_t)h->lds_max) h->trio_enabled = false;
     if (getenv("CFD_TRIO_CHUNK")) {
         h->trio_chunk = atoi(getenv("CFD_TRIO_CHUNK"));
         if (h->trio_chunk < 1) h->trio_chunk = 1;
@@ -3050,7 +3058,7 @@ const char* cfd_kernel_name(cfd_handle* h) {
     if (!h) return "";
     const bool fast = (h->p.flags & CFD_FLAG_FAST_MATH) != 0;
     if (!h->two_d) {
-        if ((h->p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && h->variant == 9))
+        if ((h->p.flags & CFD_FLAG_SIMPLE_KERNEL) || !h->march3_ok || (!fast && (h->variant == 9 || (!h->march3_strict_ok && h->variant < 0))))
             return fast ? "sweep3d_simple<fast>" : "sweep3d_simple<strict>";
         if (fast && (h->variant < 1 || h->variant > 5)) return "sweep3d_stream<fast>";
         return fast ? "sweep3d_march<fast>" : "sweep3d_march<strict>";

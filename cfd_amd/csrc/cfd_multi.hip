@@ -571,6 +571,29 @@ int cfd_multi_read_fields(cfd_multi* m, int slot_rel, double* const out[CFD_NPRO
     return CFD_OK;
 }
 
+int cfd_multi_write_fields(cfd_multi* m, int slot_rel, const double* const in[CFD_NPROP]) {
+    if (!m || !in) return fail(CFD_E_ARG, "cfd_multi_write_fields: null pointer");
+    M_CFD(cfd_multi_sync(m));
+    for (Slab& s : m->slab) {
+        const double* f[CFD_NPROP];
+        for (int k = 0; k < CFD_NPROP; ++k) {
+            if (!in[k]) return fail(CFD_E_ARG, "cfd_multi_write_fields: null input pointer");
+            f[k] = in[k] + (size_t)s.x0 * m->plane;
+        }
+        M_CFD(cfd_write_fields(s.h, slot_rel, f));
+    }
+    return CFD_OK;
+}
+
+int cfd_multi_set_time(cfd_multi* m, int curr_mod_time, int curr_abs_time) {
+    if (!m) return fail(CFD_E_ARG, "cfd_multi_set_time: null handle");
+    M_CFD(cfd_multi_sync(m));
+    for (Slab& s : m->slab) M_CFD(cfd_set_time(s.h, curr_mod_time, curr_abs_time));
+    m->cmt = curr_mod_time;
+    m->cat = curr_abs_time;
+    return CFD_OK;
+}
+
 int cfd_multi_time(cfd_multi* m, int* curr_mod_time, int* curr_abs_time) {
     if (!m || !curr_mod_time || !curr_abs_time) return fail(CFD_E_ARG, "cfd_multi_time: null pointer");
     *curr_mod_time = m->cmt;

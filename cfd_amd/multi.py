@@ -102,6 +102,29 @@ class MultiGraph:
         check(self._lib.cfd_multi_read_fields(self._h, int(slot_rel), _capi.ptr_array(out)))
         return out
 
+    def write_fields(self, fields, slot_rel=0):
+        f = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in fields]
+        if len(f) != _capi.CFD_NPROP or any(x.size != self.n for x in f):
+            raise ValueError("fields must be 7 arrays of nx*ny*nz values")
+        check(self._lib.cfd_multi_write_fields(self._h, int(slot_rel), _capi.ptr_array(f)))
+        return self
+
+    def set_time(self, curr_mod_time, curr_abs_time):
+        check(self._lib.cfd_multi_set_time(self._h, int(curr_mod_time), int(curr_abs_time)))
+        return self
+
+    def checkpoint(self):
+        """(currModTime, currAbsTime, [fields of slot_rel 0, 1, 2]) of the local slabs: everything a run needs to resume."""
+        cmt, cat = self._time()
+        return cmt, cat, [self.read_fields(r) for r in range(3)]
+
+    def restore(self, state):
+        cmt, cat, slots = state
+        self.set_time(cmt, cat)
+        for r in range(3):
+            self.write_fields(slots[r], r)
+        return self
+
     def _time(self):
         a, b = ctypes.c_int(), ctypes.c_int()
         check(self._lib.cfd_multi_time(self._h, ctypes.byref(a), ctypes.byref(b)))

@@ -40,6 +40,13 @@ enum {
     CFD_E_STATE = -4     /* call not valid in the handle's current state */
 };
 
+/* Arithmetic.  Default ("strict"): the reference's operation order, no fused contraction, correctly rounded
+ * division and square root -- bit-identical to the reference arithmetic (as restated by the CPU oracle) for finite
+ * fields.  Divisions and square roots whose operands are Temperature, Density, viscosity or the cell volume use the
+ * hardware sequences without their operand scaling, which are the IEEE results for operands in the middle of the
+ * exponent range (|x| between about 2^-767 and 2^+970); tests pin bit-equality with the oracle on fields scaled from
+ * 1e-300 to 1e+250.  NaN fields, and a -0 numerator of such a division, are outside what is reproduced bit for bit
+ * (+0 and -0 are not told apart anywhere).  CFD_FLAG_FAST_MATH: see below. */
 /* flags for cfd_params.flags */
 enum {
     CFD_FLAG_DEFAULT = 0,
@@ -355,6 +362,15 @@ int cfd_multi_total_density(cfd_multi *m, double *out);
 int cfd_multi_read_fields(cfd_multi *m, int slot_rel, double *const out[CFD_NPROP]);
 
 int cfd_multi_time(cfd_multi *m, int *curr_mod_time, int *curr_abs_time);
+
+/* State restore of a decomposed run (the reference keeps its state only in the solve loop's accumulator,
+ * src/Main.hs:278-306): cfd_write_fields / cfd_set_time on every local slab, in[i] holding the planes of all local
+ * slabs as cfd_multi_read_fields returns them; the handle's own time counters follow.  The slabs' ghost planes need
+ * no attention: every step begins with an exchange of the current slot.  To restore: create the handle from any
+ * fields of the right shape, cfd_multi_set_time, then cfd_multi_write_fields for slot_rel 0, 1, 2.  (Do not call
+ * cfd_write_fields / cfd_set_time on the handles cfd_multi_slab returns: the cfd_multi's counters would not follow.) */
+int cfd_multi_write_fields(cfd_multi *m, int slot_rel, const double *const in[CFD_NPROP]);
+int cfd_multi_set_time(cfd_multi *m, int curr_mod_time, int curr_abs_time);
 
 /* Blocks until everything queued by the handle has finished on every device. */
 int cfd_multi_sync(cfd_multi *m);

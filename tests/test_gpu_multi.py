@@ -222,3 +222,24 @@ def test_slabs_whose_chunks_next_to_a_neighbour_are_shorter(n, shape, margin, mo
         g.step(1)
         m.step(1)
         _assert_same(m, g, "step %d" % step)
+
+
+@pytest.mark.parametrize("flags,shape,n", [(FAST, (40, 300, 1), 3), (0, (12, 9, 7), 2), (FAST, (21, 18, 19), 4)])
+def test_checkpoint_restore_of_a_decomposed_run_is_bitwise(flags, shape, n):
+    """Four steps on n slabs, checkpoint (three slots + time counters), restore into a NEW slab handle created from
+    unrelated fields, three more steps: bit-identical, slot for slot, to seven straight undecomposed steps."""
+    params, fields, active = small_case(shape[0], shape[1], shape[2], 71)
+    ref = _single(params, fields, active, flags)
+    ref.step(7)
+    a = _multi(params, fields, active, flags, n)
+    a.step(4)
+    state = a.checkpoint()
+    a.close()
+    junk = [np.full_like(np.asarray(f, dtype=np.float64), 1.0 + k) for k, f in enumerate(fields)]
+    if shape[2] == 1:
+        junk[2][:] = 0.0        # the 2-D form holds no W
+    c = _multi(params, junk, active, flags, n)
+    c.restore(state)
+    assert (c.currModTime, c.currAbsTime) == (4 % 3, 4)
+    c.step(3)
+    _assert_same(c, ref, "restored")

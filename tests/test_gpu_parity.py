@@ -1131,3 +1131,28 @@ def test_strict_tiled_3d_matches_per_cell_at_256_cube():
         want = gb.read_fields(rel)
         for k in range(7):
             assert bits_equal(got[rel][k], want[k]), (rel, PROPS[k])
+
+
+@pytest.mark.parametrize("what,t_scale,rho_scale", [("tiny T", 1e-240, 1.0), ("subnormal-range T", 1e-300, 1.0),
+                                                    ("huge T", 1e200, 1.0), ("tiny Density", 1.0, 1e-250),
+                                                    ("huge Density", 1.0, 1e250), ("small T", 1e-200, 1.0)])
+@pytest.mark.parametrize("shape", [(12, 9, 1), (7, 6, 5)])
+def test_strict_kernels_far_outside_the_physical_range(what, t_scale, rho_scale, shape):
+    """The strict kernels divide and take square roots of Temperature, Density and viscosity with the compiler's
+    sequences minus their operand scaling (sweep_math.h: div_normal, sqrt_normal), which equal IEEE division and
+    square root for operands in the middle of the exponent range.  Pinned here well beyond that range (fields scaled
+    by 1e-300 .. 1e+250, where products under- and overflow): one sweep still equals the oracle bit for bit."""
+    params, fields, active = small_case(shape[0], shape[1], shape[2], seed=3)
+    fields = [np.array(f, dtype=np.float64) for f in fields]
+    fields[4] *= t_scale
+    fields[3] *= rho_scale
+    g = _gpu_graph(params, fields, active, 0)
+    b = _oracle(params, fields, active, pow_mode=1)
+    with np.errstate(all="ignore"):
+        g.sweep(True)
+        b.sweep(True)
+    fg, fb = g.read_fields(0), b.read_fields(0)
+    for k in range(7):
+        a, c = np.asarray(fg[k]), np.asarray(fb[k])
+        both_nan = np.isnan(a) & np.isnan(c)
+        assert bits_equal(np.where(both_nan, 0.0, a), np.where(both_nan, 0.0, c)), (what, PROPS[k])
