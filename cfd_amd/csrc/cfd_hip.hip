@@ -2103,6 +2103,35 @@ static void trio_plan(cfd_handle* h) {
     h->trio_first = p.ghost_lo ? ch - margin : ch;
 }
 
+// Chunk lengths of the kernels that fuse sweeps, for h->cus compute units (the device's, or the handle's share of
+// them where several handles run on one device at the same time).
+static void plan_chunks(cfd_handle* h) {
+    const cfd_params* p = &h->p;
+    if (getenv("CFD_PAIR_CHUNK")) {
+        h->pair_chunk = atoi(getenv("CFD_PAIR_CHUNK"));
+    } else {
+        // The two-sweeps kernel computes five extra rows per chunk, so chunks should be long; two of its
+        // blocks fit a CU, and the whole grid running as one round of blocks was the fastest shape measured.
+        const int cus = h->cus;
+        // most chunks whose blocks (tile_plan: the narrow last tile of a row shares blocks) fit one round
+        int chunks = 1;
+        for (int c = 2 * cus; c > 1; --c) {
+            const TilePlan tp = tile_plan(p->ny, 240, 256, 4, c);
+            if (tp.nfull * c + tp.npacked <= 2 * cus) { chunks = c; break; }
+        }
+        h->pair_chunk = (p->nx + chunks - 1) / chunks;
+        if (h->pair_chunk < 32) h->pair_chunk = 32;
+    }
+    if (h->pair_chunk < 1) h->pair_chunk = 1;
+    if (getenv("CFD_TRIO_CHUNK")) {
+        h->trio_chunk = atoi(getenv("CFD_TRIO_CHUNK"));
+        if (h->trio_chunk < 1) h->trio_chunk = 1;
+        h->trio_first = h->trio_chunk;
+    } else {
+        trio_plan(h);
+    }
+}
+
 // The strict 2-D sweep without the filter, LEAN form, instantiated in cfd_strict2d_lean.hip (compiled with the
 // minimum-register scheduling strategy, under which it fits 256 registers: two waves per SIMD).
 extern "C" int cfd_internal_launch_strict2d_lean(const SweepConsts* K, const double* src, double* dst,
@@ -2485,6 +2514,15 @@ int cfd_internal_create_on(const cfd_params* p, const double* const fields[CFD_N
     return create_impl(p, fields, active, false, (hipStream_t)stream, out);
 }
 
+// For cfd_multi.hip: this handle runs beside others on its device and should plan its launches for `cus` compute units.
+int cfd_internal_set_cu_share(cfd_handle* h, int cus) {
+    if (!h || cus < 1) return fail(CFD_E_ARG, "cfd_internal_set_cu_share: bad argument");
+    if (h->pend.open) return fail(CFD_E_STATE, "cfd_internal_set_cu_share: a split sweep or step is open");
+    h->cus = cus;
+    plan_chunks(h);
+    return CFD_OK;
+}
+
 int cfd_create(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
                cfd_handle** out) {
     return create_impl(p, fields, active, true, nullptr, out);
@@ -2535,32 +2573,10 @@ static int create_impl(const cfd_params* p, const double* const fields[CFD_NPROP
         h->lds_max = 64 * 1024;
     h->march3_strict_ok = h->march3_ok && march3_lds_bytes<MathStrict3>(256) <= (size_t)h->lds_max;
     h->pair_enabled = getenv("CFD_PAIR") ? atoi(getenv("CFD_PAIR")) != 0 : true;
-    if (getenv("CFD_PAIR_CHUNK")) {
-        h->pair_chunk = atoi(getenv("CFD_PAIR_CHUNK"));
-    } else {
-        // The one-pass kernel computes five extra rows per chunk, so chunks should be long; two of its
-        // blocks fit a CU, and the whole grid running as one round of blocks was the fastest shape measured.
-        const int cus = h->cus;
-        // most chunks whose blocks (tile_plan: the narrow last tile of a row shares blocks) fit one round
-        int chunks = 1;
-        for (int c = 2 * cus; c > 1; --c) {
-            const TilePlan tp = tile_plan(p->ny, 240, 256, 4, c);
-            if (tp.nfull * c + tp.npacked <= 2 * cus) { chunks = c; break; }
-        }
-        h->pair_chunk = (p->nx + chunks - 1) / chunks;
-        if (h->pair_chunk < 32) h->pair_chunk = 32;
-    }
-    if (h->pair_chunk < 1) h->pair_chunk = 1;
     h->trio_enabled = h->pair_enabled && (getenv("CFD_TRIO") ? atoi(getenv("CFD_TRIO")) != 0 : true);
     h->trio_nts = getenv("CFD_TRIO_NTS") && atoi(getenv("CFD_TRIO_NTS")) == 128 ? 128 : 256;
     if ((size_t)TRIO_LDS_ROWS * h->trio_nts * sizeof(double) > (size_t)h->lds_max) h->trio_enabled = false;
-    if (getenv("CFD_TRIO_CHUNK")) {
-        h->trio_chunk = atoi(getenv("CFD_TRIO_CHUNK"));
-        if (h->trio_chunk < 1) h->trio_chunk = 1;
-        h->trio_first = h->trio_chunk;
-    } else {
-        trio_plan(h);
-    }
+    plan_chunks(h);
     h->cmt = 0; h->cat = 0;
     h->chunk = 32;
     h->chunk_auto = true;

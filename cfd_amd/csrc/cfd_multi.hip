@@ -31,6 +31,7 @@
 
 extern "C" int cfd_internal_fail(int code, const char* msg);     // cfd_hip.hip: sets cfd_last_error's text
 // cfd_hip.hip: cfd_create on a stream the caller owns (the slab launches there from the start)
+extern "C" int cfd_internal_set_cu_share(cfd_handle* h, int cus);   // cfd_hip.hip: plan launches for a share of the device
 extern "C" int cfd_internal_create_on(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
                                       void* stream, cfd_handle** out);
 
@@ -244,8 +245,10 @@ bool env_flag(const char* name, bool dflt) {
     return e ? atoi(e) != 0 : dflt;
 }
 
-int streams_for(cfd_multi* m, int device, int* index) {
-    for (size_t i = 0; i < m->streams.size(); ++i)
+// own_pair: a compute / side stream pair for this slab alone (at most two slabs on the device: four hardware queues per
+// process); otherwise the slabs of a device share one pair.
+int streams_for(cfd_multi* m, int device, int* index, bool own_pair = false) {
+    for (size_t i = 0; i < m->streams.size() && !own_pair; ++i)
         if (m->streams[i].device == device) { *index = (int)i; return CFD_OK; }
     DeviceStreams d{device, nullptr, nullptr};
     M_HIP(hipSetDevice(device));
@@ -260,16 +263,25 @@ int streams_for(cfd_multi* m, int device, int* index) {
 }
 
 // Creates the slab `s` (rank, device, x0, x1 set) from the slab's own fields / mask (owned planes only).
-int make_slab(cfd_multi* m, Slab& s, const double* const fields[CFD_NPROP], const uint8_t* active, int extra_flags) {
+// on_device: how many slabs of this handle run on the slab's device.
+int make_slab(cfd_multi* m, Slab& s, const double* const fields[CFD_NPROP], const uint8_t* active, int extra_flags,
+              int on_device = 1) {
     cfd_params q = m->p;
     q.nx = s.x1 - s.x0;
     q.device = s.device;
     q.flags = m->p.flags | extra_flags;
     q.ghost_lo = s.rank > 0;
     q.ghost_hi = s.rank < m->world - 1;
-    M_CFD(streams_for(m, s.device, &s.ds));
+    // Two slabs on one device run side by side, each on streams of its own and planning its launches for half the
+    // compute units; more than two share one pair of streams (their launches then follow one another).
+    M_CFD(streams_for(m, s.device, &s.ds, on_device == 2));
     M_CFD(cfd_internal_create_on(&q, fields, active, (void*)main_of(m, s), &s.h));
     M_HIP(hipSetDevice(s.device));
+    if (on_device == 2) {
+        int cus = 0;
+        M_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s.device));
+        M_CFD(cfd_internal_set_cu_share(s.h, cus / 2 > 0 ? cus / 2 : 1));
+    }
     M_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     M_HIP(hipEventCreateWithFlags(&s.edge, hipEventDisableTiming));
     M_HIP(hipEventCreateWithFlags(&s.side_done, hipEventDisableTiming));
@@ -359,7 +371,9 @@ int cfd_multi_create(const cfd_params* p, int n_slabs, const int32_t* devices, i
         s.x1 = (int)((long)p->nx * (i + 1) / n_slabs);
         const double* f[CFD_NPROP];
         for (int k = 0; k < CFD_NPROP; ++k) f[k] = fields[k] + (size_t)s.x0 * m->plane;
-        rc = make_slab(m, s, f, active + (size_t)s.x0 * m->plane, extra);
+        int on_device = 0;
+        for (int k = 0; k < n_slabs; ++k) on_device += dev[k] == dev[i] ? 1 : 0;
+        rc = make_slab(m, s, f, active + (size_t)s.x0 * m->plane, extra, on_device);
     }
     if (rc == CFD_OK && transport == CFD_TRANSPORT_RCCL && n_slabs > 1) {
         std::vector<ncclComm_t> comms(n_slabs);
