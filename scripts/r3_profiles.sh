@@ -8,7 +8,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 NSTEP=6 bash scripts/pmc.sh $TAG/pmc2d > $O/pmc2d.log 2>&1 || { tail -20 $O/pmc2d.log; exit 1; }
 python3 scripts/pmc_summary.py $TAG/pmc2d > $O/pmc2d_summary.txt
-NX=512 NY=512 NZ=512 NSWEEP=3 NSTEP=2 bash scripts/pmc.sh $TAG/pmc3d > $O/pmc3d.log 2>&1 || { tail -20 $O/pmc3d.log; exit 1; }
+NX=512 NY=512 NZ=512 NSWEEP=4 NSTEP=2 bash scripts/pmc.sh $TAG/pmc3d > $O/pmc3d.log 2>&1 || { tail -20 $O/pmc3d.log; exit 1; }
 python3 scripts/pmc_summary.py $TAG/pmc3d > $O/pmc3d_summary.txt
 python3 scripts/record_traffic.py $O/pmc2d_summary.txt profiles/r03/final_pmc_4096sq.txt $O/pmc3d_summary.txt profiles/r03/final_pmc_512cube.txt 512 > $O/traffic.log
 cp profiles/traffic.json $O/traffic.json
