@@ -581,7 +581,9 @@ def main():
         ("synthetic_3d %dx%dx%d per GPU" % (a.nx, a.ny, a.nz))
     if a.strong:
         workload += " (rank 0's share of %d global x-planes)" % global_nx
-    kernel_name = base_name
+    # the kernel the timed steps ran in; cfd_kernel_name names the single sweep's kernel of the handle
+    kernel_name = dominant["kernel"].split(" ")[0] if dominant["kernel"].startswith(("sweep2d_trio", "sweep2d_pair")) \
+        else base_name
     out = {
         "metric": "fp64 cell-updates/sec",
         "value": updates / elapsed,
