@@ -1178,8 +1178,10 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
 //
 // Lanes of a stage group: the tile's own columns first, then the columns +1, -1, +2, -2, +3, -3 beside the tile
 // (stage 0 needs all six, stage 1 the first four, stage 2 the first two: the outermost pair of a stage only sends
-// messages and stored values inwards); further lanes idle.  Tiles: widths are multiples of 16 columns, as equal as
-// possible (trio_tiles), so every block runs all its waves and stores whole 128-byte lines.
+// messages and stored values inwards); further lanes idle.  Tiles: widths are multiples of 8 columns (64 bytes), as
+// equal as possible (trio_tiles) and up to 248 of a 256-lane stage: 4096 columns are 17 tiles of 240 or 248.  (Whole
+// 128-byte lines per tile -- multiples of 16, at most 240 -- need an 18th tile there and take 3 % longer; widths that
+// are not a multiple of 8 are no faster than that.)
 // Clamp-to-self at the ends of the domain applies to each sweep separately; a stage gets it, as sweep2d_stream
 // does, from clamped row indices into its input (the producer writes only rows on which its output is defined):
 //   stage s reads input rows lo_s .. hi_s,  lo_s = min(lo0 + s, 0),  hi_s = max(hi0 - s, nx - 1).
@@ -1187,13 +1189,13 @@ sweep2d_pair(FastConsts K, const double* __restrict__ src, double* __restrict__ 
 #define CFD_TRIO_PRIO 1
 #endif
 static constexpr bool TRIO_PRIO = CFD_TRIO_PRIO != 0;
-struct TrioTiles { int ntile, lines; };
-__host__ __device__ inline TrioTiles trio_tiles(int ny, int wmax) {
-    const int lines = (ny + 15) / 16, per = wmax / 16;
-    return TrioTiles{(lines + per - 1) / per, lines};
+struct TrioTiles { int ntile, lines, gran; };
+__host__ __device__ inline TrioTiles trio_tiles(int ny, int wmax, int gran) {
+    const int lines = (ny + gran - 1) / gran, per = wmax / gran;
+    return TrioTiles{(lines + per - 1) / per, lines, gran};
 }
 __host__ __device__ inline int trio_tile_start(const TrioTiles& tp, int i) {
-    return (int)(((long)i * tp.lines) / tp.ntile) * 16;
+    return (int)(((long)i * tp.lines) / tp.ntile) * tp.gran;
 }
 
 // LDS of the three-sweeps kernel, in rows of NTS doubles: messages [3 stages][2][6], stored values of stage 0's
@@ -1399,14 +1401,14 @@ __device__ __forceinline__ void trio_stage(const FastConsts& K, const double* __
 template <int NTS, int MINW, bool FILTER>
 __global__ void __launch_bounds__(3 * NTS, MINW)
 sweep2d_trio(FastConsts K, const double* __restrict__ src, double* __restrict__ dst, const uint8_t* __restrict__ active,
-             int nx, int ny, int lo0, int hi0, int ch, int x_first, int by0, int wmax, const double* __restrict__ fpp,
-             double* __restrict__ fprev) {
+             int nx, int ny, int lo0, int hi0, int ch, int x_first, int by0, int wmax, int gran,
+             const double* __restrict__ fpp, double* __restrict__ fprev) {
     extern __shared__ double smem[];
     const int t = threadIdx.x;
     const int first_lane = (int)__builtin_amdgcn_readfirstlane(t) & ~63;     // first lane of this wave (scalar)
     const int stage = first_lane / NTS;
     const int tl = t - stage * NTS, wave0 = first_lane - stage * NTS;
-    const TrioTiles tp = trio_tiles(ny, wmax);
+    const TrioTiles tp = trio_tiles(ny, wmax, gran);
     const unsigned wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int bx = (int)(wg % (unsigned)tp.ntile), by = by0 + (int)(wg / (unsigned)tp.ntile);
     const int ytile = trio_tile_start(tp, bx);
@@ -2054,8 +2056,14 @@ static int march_chunk(int nplanes, long tiles, long slots) {
 // x-planes per block of the three-sweeps kernel.  One block (nts == 256) or two (128) run on a compute unit at a time,
 // every block of a launch takes the same time per iteration, and a block of `ch` planes runs ch + 10 iterations
 // (the three stages follow one another three rows apart): the launch takes ceil(blocks / slots) rounds of that.
+// columns a tile's width is a multiple of
+static int trio_gran() {
+    static const int g = [] { const char* e = getenv("CFD_TRIO_GRAN"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 16 ? v : 8; }();
+    return g;
+}
+static int trio_wmax(int nts) { return trio_gran() == 16 ? nts - 16 : nts - 6; }
 static int trio_chunk_for(int nx, int ny, int nts, int cus) {
-    const long slots = (nts == 128 ? 2L : 1L) * cus, tiles = trio_tiles(ny, nts - 16).ntile;
+    const long slots = (nts == 128 ? 2L : 1L) * cus, tiles = trio_tiles(ny, trio_wmax(nts), trio_gran()).ntile;
     int best = nx;
     long best_cost = -1;
     for (int nchunk = 1; nchunk <= nx; ++nchunk) {
@@ -2412,8 +2420,8 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
     }
     hipEvent_t ea = h->timing ? ev.a : nullptr, eb = h->timing ? ev.b : nullptr;
     const uint8_t* act = h->d_active + GHOST * h->plane;
-    const int ch = h->trio_chunk, nts = h->trio_nts, wmax = nts - 16;
-    const TrioTiles tp = trio_tiles(p.ny, wmax);
+    const int ch = h->trio_chunk, nts = h->trio_nts, wmax = trio_wmax(nts), gran = trio_gran();
+    const TrioTiles tp = trio_tiles(p.ny, wmax, gran);
     const int nchunk = trio_nchunk(h);
     if (c1 < 0) c1 = nchunk;
     if (c1 <= c0) return CFD_OK;        // empty range: nothing launched
@@ -2429,7 +2437,7 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
             attr_set[h->device & 63] = true;                                                       \
         }                                                                                          \
         hipExtLaunchKernelGGL(kern, dim3(tp.ntile * (c1 - c0)), dim3(3 * NTS), lds, h->stream, ea, eb, 0, h->KF,    \
-                              src, dst, act, p.nx, p.ny, lo0, hi0, ch, h->trio_first, c0, wmax, fpp, fprev); \
+                              src, dst, act, p.nx, p.ny, lo0, hi0, ch, h->trio_first, c0, wmax, gran, fpp, fprev); \
     } while (0)
     if (nts == 128) { if (fpp) LAUNCH_TRIO(128, 3, true); else LAUNCH_TRIO(128, 3, false); }
     else { if (fpp) LAUNCH_TRIO(256, 3, true); else LAUNCH_TRIO(256, 3, false); }
