@@ -74,8 +74,10 @@ def parse():
                          "measure what the decomposition itself costs")
     ap.add_argument("--no-preflight", action="store_true",
                     help="N > 1: skip the bit-for-bit check of the decomposition against an undecomposed run before timing")
-    ap.add_argument("--preflight-timeout", type=float, default=240.0,
-                    help="N > 1: seconds the rendezvous and the pre-flight may take before the rank exits with status 3")
+    ap.add_argument("--preflight-timeout", type=float, default=420.0,
+                    help="N > 1: seconds the rendezvous, the pre-flight and the creation of the timed slab may take "
+                         "together before the rank exits with status 3 (three communicators are built in that time, "
+                         "on a fresh machine each library loads its device code first)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse launch + rendezvous + reduction without a GPU (gloo, no compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -326,7 +328,8 @@ def main():
     if world > 1 and c_driver:
         import datetime
         # control plane only; the halo planes go through the library's RCCL
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+        # (its timeout also bounds how far apart the ranks may reach a control-plane collective)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
     elif world > 1:
         init_rccl(torch.device("cuda", local_rank))     # rank, world size and rendezvous from the environment
     red_dev = "cpu" if (world > 1 and c_driver) else "cuda"
