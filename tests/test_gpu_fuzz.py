@@ -2,7 +2,7 @@
 
 The hand-picked shapes of test_gpu_parity.py straddle the tile edges the author thought of; these draw the extents
 from every value next to a tile, wave or cache-line boundary of the launch shapes (2-D: 62/63/64, 126/128, 240/241,
-254/256, two tiles 480/496; 3-D: 12/14/16 and their multiples) and combine them with chunk lengths of 1 to 7, the
+248/249, 254/256, two tiles 480/496; 3-D: 12/14/16 and their multiples) and combine them with chunk lengths of 1 to 7, the
 default 32 and primes, strict and re-associated arithmetic, with and without an identically zero V."""
 import numpy as np
 import pytest
@@ -11,8 +11,8 @@ from helpers import PROPS, bits_equal, oracle_params, small_case
 
 pytestmark = pytest.mark.gpu
 
-EDGES_2D = [1, 2, 3, 15, 16, 17, 62, 63, 64, 65, 125, 126, 127, 128, 239, 240, 241, 242, 253, 254, 255, 256, 257,
-            480, 481, 495, 496, 497]
+EDGES_2D = [1, 2, 3, 7, 8, 9, 15, 16, 17, 62, 63, 64, 65, 125, 126, 127, 128, 239, 240, 241, 242, 247, 248, 249, 253, 254, 255,
+            256, 257, 480, 481, 495, 496, 497]
 EDGES_3D = [1, 2, 11, 12, 13, 14, 15, 16, 17, 23, 24, 25, 28, 29, 31, 32, 33]
 
 
@@ -32,10 +32,17 @@ def test_random_shapes_against_the_oracle(seed, monkeypatch):
             nx, ny, nz = int(rng.integers(1, 40)), int(rng.choice(EDGES_2D)), 1
             nx = min(nx, max(1, 6000 // ny))
         monkeypatch.setenv("CFD_CHUNK", str(chunk))
+        # planes per block of the one-launch step (2-D, re-associated arithmetic): chosen by the library, or forced short
+        trio_chunk = int(rng.choice([0, 0, 1, 2, 3, 5, 8, 31]))
+        if trio_chunk:
+            monkeypatch.setenv("CFD_TRIO_CHUNK", str(trio_chunk))
+        else:
+            monkeypatch.delenv("CFD_TRIO_CHUNK", raising=False)
         params, fields, active = small_case(nx, ny, nz, seed=1000 * seed + c, zero_v=bool(rng.random() < 0.3))
         p = dict(params)
         p["flags"] = 4 if fast else 0
-        what = "%s %s %dx%dx%d chunk %d" % ("3-D" if three else "2-D", "fast" if fast else "strict", nx, ny, nz, chunk)
+        what = "%s %s %dx%dx%d chunk %d / %d" % ("3-D" if three else "2-D", "fast" if fast else "strict", nx, ny, nz, chunk,
+                                                 trio_chunk)
         g = AdjGraph(p, fields, active)
         b = OracleB(oracle_params(params), fields, active, pow_mode=1, nthreads=4)
         if not fast:
