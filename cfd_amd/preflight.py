@@ -44,16 +44,17 @@ def first_difference(got, want, x0, plane):
     return None
 
 
-def run(rank, world, flags, nz, make_slab, device=-1, steps=3, dt=1e-7):
+def run(rank, world, flags, nz, make_slab, device=-1, steps=3, dt=1e-7, make_ref=None):
     """make_slab(name, params, fields, active, x0, x1): this rank's slab of the decomposed run of grid `name` (params /
     fields / active of planes x0 .. x1-1 only) with step(n), read_fields(slot_rel), total_density() (summed over
-    all ranks) and close().  Returns {"ok", "cases", "steps", "detail"}."""
+    all ranks) and close().  make_ref(params, fields, active): the undecomposed run with the same verbs (default: the
+    library on this rank's GPU).  Returns {"ok", "cases", "steps", "detail"}."""
     report = {"ok": True, "steps": steps, "cases": [], "detail": None}
     for name, params, fields, active in grids(world, nz):
         params = dict(params, dt=dt, flags=flags, device=device)
         nx, plane = params["nx"], params["ny"] * params["nz"]
         x0, x1 = slab_range(nx, rank, world)
-        ref = AdjGraph(params, fields, active)
+        ref = (make_ref or AdjGraph)(params, fields, active)
         sl = make_slab(name, dict(params, nx=x1 - x0), [np.ascontiguousarray(f[x0 * plane:x1 * plane]) for f in fields],
                        np.ascontiguousarray(active[x0 * plane:x1 * plane]), x0, x1)
         detail = None

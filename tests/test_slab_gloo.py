@@ -138,3 +138,71 @@ def test_w_in_one_slab_only_forces_the_general_form_on_every_rank():
         assert bool(flags & 2) == (rank == 0), (rank, flags)        # rank 1 keeps W by itself
         for k in range(7):
             assert bits_equal(got[k], want[k][x0 * ny:x1 * ny]), (rank, k)
+
+
+def _preflight_rank(rank, world, port, spoil, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from helpers import oracle_params
+    from oracle import OracleB
+    from cfd_amd import preflight
+    from cfd_amd.slab import DistComm, SlabGraph
+    from slab_double import OracleSlabBackend
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+
+    class Whole:
+        """The undecomposed run on the CPU oracle, with the verbs the pre-flight uses."""
+
+        def __init__(self, params, fields, active):
+            self.o = OracleB(oracle_params(params), fields, active, pow_mode=1)
+        step = lambda self, n: self.o.step(n)
+        read_fields = lambda self, rel: self.o.read_fields(rel)
+        total_density = lambda self: self.o.total_density()
+        close = lambda self: self.o.close()
+
+    class Slab:
+        def __init__(self, params, fields, active):
+            self.g = SlabGraph(params, fields, active, rank=rank, world=world, comm=DistComm(rank, world),
+                               backend_cls=OracleSlabBackend)
+        step = lambda self, n: self.g.step(n)
+        total_density = lambda self: self.g.total_density()
+        close = lambda self: None
+
+        def read_fields(self, rel):
+            out = [np.array(f) for f in self.g.read_fields(rel)]
+            if spoil and rank == world - 1 and rel == 1:
+                out[3][5] = np.nextafter(out[3][5], 1e9)        # one Density value of the last rank off by one ulp
+            return out
+
+    try:
+        rep = preflight.run(rank, world, 0, 1, lambda name, p, f, m, x0, x1: Slab(p, f, m), steps=2, make_ref=Whole)
+        q.put((rank, rep))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("spoil", [False, True])
+def test_preflight_protocol_over_gloo(spoil):
+    """The pre-flight a multi-GPU bench runs before it times anything, with two ranks over gloo and the CPU oracle in
+    place of the GPU on both sides of the comparison: every rank compares its planes of the decomposed run with the
+    undecomposed one bit for bit; a single value that is off by one ulp on one rank is named by that rank only."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_preflight_rank, args=(r, world, port, spoil, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    reports = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        rep = reports[rank]
+        assert len(rep["cases"]) == 2 and rep["steps"] == 2
+        if spoil and rank == world - 1:
+            assert not rep["ok"] and "rank 1 of 2" in rep["detail"] and "slot -1" in rep["detail"] and "Density" in rep["detail"]
+        else:
+            assert rep["ok"] and rep["detail"] is None, rep
