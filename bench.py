@@ -312,6 +312,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CFD_BENCH_ONE_DEVICE"):
+        # rehearsal of the failure path on a one-GPU machine: every rank on device 0, where no communicator can be
+        # built (RCCL refuses two ranks on one device); the job must end with a non-zero status, not hang
+        local_rank = 0
     if world != a.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
     if a.dry_run:
