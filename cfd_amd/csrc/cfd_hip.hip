@@ -2089,13 +2089,15 @@ static void trio_span(const cfd_handle* h, int c, int* xs, int* xe) {
 // Chunk lengths of the three-sweeps kernel for this handle.  Undecomposed: uniform (trio_chunk_for).  A slab launches
 // the chunks next to a neighbour only once the neighbour's planes have arrived, i.e. later than the others by the
 // duration of the exchange, and all blocks of a step should end together: those chunks get `margin` planes fewer
-// (env CFD_TRIO_EDGE_MARGIN, default 24 = about 60 us of the kernel's 2.4 us per plane), the others share the rest.
+// (env CFD_TRIO_EDGE_MARGIN, default 32 = about 77 us of the kernel's 2.4 us per plane: a three-plane exchange between
+// two processes is expected to take 30-60 us, and ten planes too many cost the other chunks half a percent, ten too
+// few cost the step 24 us), the others share the rest.
 static void trio_plan(cfd_handle* h) {
     const cfd_params& p = h->p;
     const int ch0 = trio_chunk_for(p.nx, p.ny, h->trio_nts, h->cus);
     h->trio_chunk = h->trio_first = ch0;
     const int edges = (p.ghost_lo ? 1 : 0) + (p.ghost_hi ? 1 : 0), nchunk = (p.nx + ch0 - 1) / ch0;
-    int margin = getenv("CFD_TRIO_EDGE_MARGIN") ? atoi(getenv("CFD_TRIO_EDGE_MARGIN")) : 24;
+    int margin = getenv("CFD_TRIO_EDGE_MARGIN") ? atoi(getenv("CFD_TRIO_EDGE_MARGIN")) : 32;
     if (margin > ch0 / 4) margin = ch0 / 4;
     if (!edges || nchunk < 3 || margin < 1) return;
     // edges * (ch - margin) + (nchunk - edges) * ch >= nx, with the last chunk (what is left) no longer than ch - margin
