@@ -75,9 +75,10 @@ enum {
  *
  * Slab decomposition (one handle per GPU): the handle owns nx planes.  ghost_lo / ghost_hi
  * say whether a neighbouring slab exists below x = 0 / above x = nx-1; if so the handle keeps
- * one extra plane on that side which the host fills before every sweep (cfd_halo_*), and the
- * clamp-at-the-domain-edge rule of offsetPosition (src/SolutionDomain.hs:434-448) applies
- * only on sides without a ghost plane.
+ * three extra planes on that side, of which the host fills the nearest one before every sweep
+ * (cfd_halo_planes), the nearest two before the two-sweeps pass, all three before a one-pass step
+ * (cfd_halo_planes_depth), and the clamp-at-the-domain-edge rule of offsetPosition
+ * (src/SolutionDomain.hs:434-448) applies only on sides without ghost planes.
  */
 typedef struct cfd_params {
     int32_t nx, ny, nz;
