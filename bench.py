@@ -488,6 +488,10 @@ def main():
     sclk = []
     g.graph.set_timing(True)
     g.graph.sweep_timing(reset=True)
+    timed_exchange = c_driver and hasattr(g, "m")
+    if timed_exchange:
+        g.m.exchange_timing(reset=True)
+        g.m.set_exchange_timing(True)
     t0 = time.perf_counter()
     for i in range(a.steps):
         g.step(1)
@@ -500,6 +504,13 @@ def main():
     pair_ms, pair_launches = g.graph.kernel_timing(2, reset=True)
     trio_ms, trio_launches = g.graph.kernel_timing(3, reset=True)
     g.graph.set_timing(False)
+    exchange = None
+    if timed_exchange:
+        g.m.set_exchange_timing(False)
+        x_ms, x_n = g.m.exchange_timing(reset=True)
+        if x_n:
+            # rank 0's figure: from the moment its stream gets to the exchange to the arrival of its ghost planes
+            exchange = {"per_step": x_n / a.steps, "avg_ms": x_ms / x_n, "ms_per_step": x_ms / a.steps}
     base_name = g.graph.kernel_name()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -625,6 +636,7 @@ def main():
                              "which this value is measured on unless --arith strict: <= 1e-13 of the field scale per "
                              "sweep against strict; the strict kernels' rate is under \"strict\"",
                    "fast_vs_strict_one_step_on_this_workload": fast_vs_strict,
+                   "halo_exchange": exchange,
                    "preflight": preflight_report if world > 1 else "not applicable at N = 1 (no decomposition)",
                    "fields_finite_at_end": bool(final_density == final_density and abs(final_density) != float("inf"))},
         # the launch kind that takes most of the timed region; every kind is listed under "kernels"

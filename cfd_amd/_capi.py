@@ -22,7 +22,7 @@ EXPORTS = [
     "cfd_total_density", "cfd_total_density_noalloc", "cfd_read_fields", "cfd_write_fields", "cfd_set_time", "cfd_property_slice", "cfd_time", "cfd_last_error", "cfd_halo_planes", "cfd_halo_planes_depth", "cfd_set_ghost_active", "cfd_pair_available",
     "cfd_set_ghost_active_depth", "cfd_one_pass_step_available", "cfd_step_one_pass", "cfd_step_one_pass_begin", "cfd_step_one_pass_end_on",
     "cfd_multi_create", "cfd_multi_create_rank", "cfd_comm_unique_id", "cfd_multi_destroy", "cfd_multi_step", "cfd_multi_total_density",
-    "cfd_multi_read_fields", "cfd_multi_write_fields", "cfd_multi_set_time", "cfd_multi_time", "cfd_multi_sync", "cfd_multi_info", "cfd_multi_slab", "cfd_rccl_selftest",
+    "cfd_multi_read_fields", "cfd_multi_write_fields", "cfd_multi_set_time", "cfd_multi_time", "cfd_multi_sync", "cfd_multi_info", "cfd_multi_slab", "cfd_multi_set_exchange_timing", "cfd_multi_exchange_timing", "cfd_rccl_selftest",
     "cfd_stream", "cfd_set_stream", "cfd_kernel_name", "cfd_sync", "cfd_set_timing", "cfd_sweep_timing", "cfd_kernel_timing", "cfd_live_fields",
 ]
 
@@ -122,6 +122,8 @@ def load():
     L.cfd_multi_set_time.argtypes = [H, ctypes.c_int, ctypes.c_int]
     L.cfd_multi_sync.argtypes = [H]
     L.cfd_multi_info.argtypes = [H, PI, PI, PI]
+    L.cfd_multi_set_exchange_timing.argtypes = [H, ctypes.c_int]
+    L.cfd_multi_exchange_timing.argtypes = [H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     L.cfd_multi_slab.argtypes = [H, ctypes.c_int, ctypes.POINTER(H), PI, PI]
     L.cfd_rccl_selftest.argtypes = [ctypes.c_int, ctypes.c_size_t]
     for name in EXPORTS:

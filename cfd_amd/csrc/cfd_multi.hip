@@ -86,6 +86,11 @@ struct cfd_multi {
     std::vector<Slab> slab;     // the slabs this process holds, in rank order
     std::vector<DeviceStreams> streams;
     int cmt = 0, cat = 0;
+    // measurement: duration of the first local slab's ghost-plane exchanges (event pairs around them on their stream)
+    bool time_exchange = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> xev_used, xev_free;
+    double x_ms = 0.0;
+    long x_count = 0;
 };
 
 namespace {
@@ -105,6 +110,30 @@ int exchange(cfd_multi* m, int depth, bool on_side, Ready ready) {
     std::vector<Planes> pl(m->slab.size());
     for (size_t i = 0; i < m->slab.size(); ++i)
         M_CFD(cfd_halo_planes_depth(m->slab[i].h, depth, &pl[i].slo, &pl[i].shi, &pl[i].rlo, &pl[i].rhi, &pl[i].bytes));
+    // timed: from the moment the first local slab's stream gets to the exchange (its own planes are complete) to the
+    // arrival of its ghost planes, waiting for the neighbours included
+    std::pair<hipEvent_t, hipEvent_t> xev{nullptr, nullptr};
+    hipStream_t xst = nullptr;
+    if (m->time_exchange) {
+        const Slab& s0 = m->slab[0];
+        M_HIP(hipSetDevice(s0.device));
+        xst = on_side ? side_of(m, s0) : main_of(m, s0);
+        if (m->xev_free.empty()) {
+            M_HIP(hipEventCreate(&xev.first));
+            M_HIP(hipEventCreate(&xev.second));
+        } else {
+            xev = m->xev_free.back();
+            m->xev_free.pop_back();
+        }
+        M_HIP(hipEventRecord(xev.first, xst));
+    }
+    auto timed_end = [&]() -> int {
+        if (!xev.first) return CFD_OK;
+        M_HIP(hipSetDevice(m->slab[0].device));
+        M_HIP(hipEventRecord(xev.second, xst));
+        m->xev_used.push_back(xev);
+        return CFD_OK;
+    };
     if (m->transport == CFD_TRANSPORT_RCCL) {
         M_NCCL(ncclGroupStart());
         for (size_t i = 0; i < m->slab.size(); ++i) {
@@ -121,10 +150,11 @@ int exchange(cfd_multi* m, int depth, bool on_side, Ready ready) {
             }
         }
         M_NCCL(ncclGroupEnd());
-        return CFD_OK;
+        return timed_end();
     }
     for (size_t i = 0; i < m->slab.size(); ++i) {
         const Slab& s = m->slab[i];
+        if (i == 1) M_CFD(timed_end());         // the first slab's copies are queued
         M_HIP(hipSetDevice(s.device));
         hipStream_t st = on_side ? side_of(m, s) : main_of(m, s);
         for (int side = 0; side < 2; ++side) {
@@ -141,6 +171,20 @@ int exchange(cfd_multi* m, int depth, bool on_side, Ready ready) {
                 M_HIP(hipMemcpyPeerAsync(dst, s.device, src, nb.device, pl[i].bytes, st));
         }
     }
+    if (m->slab.size() == 1) M_CFD(timed_end());
+    return CFD_OK;
+}
+
+// folds the finished event pairs of the exchange timing into the accumulators (the streams must have run)
+int drain_exchange_events(cfd_multi* m) {
+    for (auto& e : m->xev_used) {
+        float ms = 0.f;
+        M_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        m->x_ms += ms;
+        m->x_count += 1;
+        m->xev_free.push_back(e);
+    }
+    m->xev_used.clear();
     return CFD_OK;
 }
 
@@ -321,6 +365,8 @@ void cfd_multi_destroy(cfd_multi* m) {
         if (s.side_done) (void)hipEventDestroy(s.side_done);
         if (s.d_sum) (void)hipFree(s.d_sum);
     }
+    for (auto* v : {&m->xev_used, &m->xev_free})
+        for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (DeviceStreams& d : m->streams) {
         (void)hipSetDevice(d.device);
         if (d.side) (void)hipStreamDestroy(d.side);
@@ -620,6 +666,23 @@ int cfd_multi_info(cfd_multi* m, int* local_slabs, int* one_pass_tail, int* over
     if (local_slabs) *local_slabs = (int)m->slab.size();
     if (one_pass_tail) *one_pass_tail = m->trio ? 2 : (m->pair ? 1 : 0);
     if (overlapped) *overlapped = (m->overlap && m->world > 1) ? 1 : 0;
+    return CFD_OK;
+}
+
+int cfd_multi_set_exchange_timing(cfd_multi* m, int enable) {
+    if (!m) return fail(CFD_E_ARG, "cfd_multi_set_exchange_timing: null handle");
+    m->time_exchange = enable != 0;
+    return CFD_OK;
+}
+
+int cfd_multi_exchange_timing(cfd_multi* m, double* total_ms, int64_t* exchanges, int reset) {
+    if (!m || !total_ms || !exchanges) return fail(CFD_E_ARG, "cfd_multi_exchange_timing: null pointer");
+    M_CFD(cfd_multi_sync(m));
+    M_HIP(hipSetDevice(m->slab[0].device));
+    M_CFD(drain_exchange_events(m));
+    *total_ms = m->x_ms;
+    *exchanges = m->x_count;
+    if (reset) { m->x_ms = 0.0; m->x_count = 0; }
     return CFD_OK;
 }
 

@@ -140,6 +140,16 @@ class MultiGraph:
         check(self._lib.cfd_multi_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, bool(c.value)
 
+    def set_exchange_timing(self, enable):
+        check(self._lib.cfd_multi_set_exchange_timing(self._h, 1 if enable else 0))
+
+    def exchange_timing(self, reset=False):
+        """(total milliseconds, number) of the first local slab's ghost-plane exchanges while the timing was on;
+        waits for the queued work first."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        check(self._lib.cfd_multi_exchange_timing(self._h, ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
     def slab(self, i):
         h, x0, x1 = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
         check(self._lib.cfd_multi_slab(self._h, int(i), ctypes.byref(h), ctypes.byref(x0), ctypes.byref(x1)))

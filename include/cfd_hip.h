@@ -382,6 +382,13 @@ int cfd_multi_sync(cfd_multi *m);
  * stream beside the interior planes. */
 int cfd_multi_info(cfd_multi *m, int *local_slabs, int *one_pass_tail, int *overlapped);
 
+/* Measurement hook: duration of the ghost-plane exchanges of the first local slab, from HIP events recorded on the
+ * exchange's stream around every exchange while the timing was enabled -- from the moment that stream gets to the
+ * exchange (the slab's own planes are complete) to the arrival of its ghost planes, the wait for the neighbours
+ * included.  cfd_multi_exchange_timing synchronises the handle first.  No counterpart in the reference. */
+int cfd_multi_set_exchange_timing(cfd_multi *m, int enable);
+int cfd_multi_exchange_timing(cfd_multi *m, double *total_ms, int64_t *exchanges, int reset);
+
 /* Local slab i: its single-slab handle (for cfd_set_timing / cfd_kernel_timing / cfd_property_slice; do not
  * step or destroy it) and its plane range [x0, x1) within the arrays given at creation. */
 int cfd_multi_slab(cfd_multi *m, int i, cfd_handle **h, int *x0, int *x1);

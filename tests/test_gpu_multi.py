@@ -243,3 +243,23 @@ def test_checkpoint_restore_of_a_decomposed_run_is_bitwise(flags, shape, n):
     assert (c.currModTime, c.currAbsTime) == (4 % 3, 4)
     c.step(3)
     _assert_same(c, ref, "restored")
+
+
+@pytest.mark.parametrize("flags,shape,n,per_step", [(FAST, (40, 300, 1), 3, 1), (0, (12, 9, 7), 2, 3), (FAST, (4, 33, 1), 2, 2)])
+def test_exchange_timing_counts_the_exchanges_of_a_step(flags, shape, n, per_step):
+    """The measurement hook of the slab driver: one exchange per step where the step is one pass, two where its tail
+    is, three otherwise; a positive duration; nothing recorded while it is off; results unchanged by it."""
+    params, fields, active = small_case(shape[0], shape[1], shape[2], 73)
+    g = _single(params, fields, active, flags)
+    m = _multi(params, fields, active, flags, n)
+    m.step(1)
+    assert m.exchange_timing() == (0.0, 0)
+    m.set_exchange_timing(True)
+    m.step(4)
+    ms, count = m.exchange_timing(reset=True)
+    assert count == 4 * per_step and ms > 0.0, (ms, count)
+    m.set_exchange_timing(False)
+    m.step(1)
+    assert m.exchange_timing() == (0.0, 0)
+    g.step(6)
+    _assert_same(m, g, "after timed steps")
