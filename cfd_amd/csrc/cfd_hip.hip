@@ -20,6 +20,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -91,6 +94,9 @@ struct cfd_handle {
     int lds_max;            // LDS bytes a workgroup may use on this device
     bool pair_enabled;      // cfd_step runs its second and third sweep in one pass (env CFD_PAIR, default on)
     int pair_chunk;         // x-planes per block of that kernel (env CFD_PAIR_CHUNK)
+    int cus_device;         // compute units of the device (cus: those this handle plans for)
+    hipStream_t interior_stream;    // the stream the open one-pass step's interior blocks were launched on
+    bool xcd_fill;          // a slab's blocks next to a neighbour are placed on the XCDs with room (env CFD_TRIO_XCD_FILL, default on)
     bool trio_enabled;      // cfd_step runs all three sweeps of a step in one pass (env CFD_TRIO, default on)
     int trio_chunk;         // x-planes per block of that kernel (env CFD_TRIO_CHUNK)
     int trio_first;         // x-planes of its first chunk (a slab's chunks next to a neighbour are shorter: see trio_plan)
@@ -428,6 +434,40 @@ sweep3d_simple(typename M::Consts K, const double* __restrict__ src, double* __r
 __device__ __forceinline__ unsigned xcd_contiguous_id(unsigned orig, unsigned nwg) {
     const unsigned q = nwg / 8u, r = nwg % 8u, xcd = orig % 8u;
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + orig / 8u;
+}
+
+// A launch that starts while another launch (of `busy` one-block-per-compute-unit workgroups) holds most of the device.
+// The hardware deals the workgroups of a launch to the XCDs in turn -- workgroup i of a launch on hardware queue q runs
+// on XCD (i + o_q) % 8, o_q a constant of the queue (measured: xcc_offset_of) -- whether or not that XCD has a compute
+// unit free, so a workgroup dealt to a full XCD waits for a whole block of the other launch to end while compute
+// units idle elsewhere (measured on a slab's one-pass step: 1.07 ms instead of 0.71).  xcd_fill_rank places the work
+// where the room is: workgroup `b` of the second launch takes a unit of work only if its XCD still has a compute unit
+// free after the first launch's share (`cap` compute units per XCD) and the earlier workgroups of this launch; it
+// returns the rank of that unit among the launch's units of work, or -1 for a workgroup that is only there to fill a
+// turn (it leaves at once).  oa, ob: the queue constants of the first and of this launch.
+// xcd_fill_grid: workgroups to launch for `units` units of work (0: they do not fit beside `busy`).
+__host__ __device__ inline int xcd_free(int busy, int cap, int xcd, int oa) {
+    const int first = (xcd - oa + 8) % 8;       // the first workgroup of the other launch that runs on this XCD
+    const int used = busy > first ? (busy - first + 7) / 8 : 0;
+    return cap > used ? cap - used : 0;
+}
+__host__ __device__ inline int xcd_fill_rank(int b, int busy, int cap, int oa, int ob) {
+    const int xcd = (b + ob) % 8, turn = b / 8;
+    if (turn >= xcd_free(busy, cap, xcd, oa)) return -1;
+    int rank = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int f = xcd_free(busy, cap, x, oa), before = turn + ((x - ob + 8) % 8 < b % 8 ? 1 : 0);
+        rank += f < before ? f : before;
+    }
+    return rank;
+}
+inline int xcd_fill_grid(int units, int busy, int cap, int oa, int ob) {
+    int total = 0;
+    for (int x = 0; x < 8; ++x) total += xcd_free(busy, cap, x, oa);
+    if (total < units) return 0;
+    int placed = 0;
+    for (int b = 0;; ++b)
+        if (xcd_fill_rank(b, busy, cap, oa, ob) >= 0 && ++placed == units) return b + 1;
 }
 
 // How the tiles of a 2-D tiled launch map to blocks.  A row of ny columns is cut into tiles of wcols; every
@@ -1401,16 +1441,25 @@ __device__ __forceinline__ void trio_stage(const FastConsts& K, const double* __
 template <int NTS, int MINW, bool FILTER>
 __global__ void __launch_bounds__(3 * NTS, MINW)
 sweep2d_trio(FastConsts K, const double* __restrict__ src, double* __restrict__ dst, const uint8_t* __restrict__ active,
-             int nx, int ny, int lo0, int hi0, int ch, int x_first, int by0, int wmax, int gran,
-             const double* __restrict__ fpp, double* __restrict__ fprev) {
+             int nx, int ny, int lo0, int hi0, int ch, int x_first, int by0, int n_first, int by1, int wmax, int gran,
+             int busy, int xcd_cap, int xcd_off, const double* __restrict__ fpp, double* __restrict__ fprev) {
     extern __shared__ double smem[];
     const int t = threadIdx.x;
     const int first_lane = (int)__builtin_amdgcn_readfirstlane(t) & ~63;     // first lane of this wave (scalar)
     const int stage = first_lane / NTS;
     const int tl = t - stage * NTS, wave0 = first_lane - stage * NTS;
     const TrioTiles tp = trio_tiles(ny, wmax, gran);
-    const unsigned wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int bx = (int)(wg % (unsigned)tp.ntile), by = by0 + (int)(wg / (unsigned)tp.ntile);
+    // busy > 0: this launch starts beside one of `busy` blocks and takes the compute units that one leaves (xcd_fill_rank)
+    int placed = 0;
+    if (busy > 0) {
+        placed = xcd_fill_rank((int)blockIdx.x, busy, xcd_cap, xcd_off & 7, (xcd_off >> 4) & 7);
+        if (placed < 0) return;
+    }
+    const unsigned wg = busy > 0 ? (unsigned)placed : xcd_contiguous_id(blockIdx.x, gridDim.x);
+    // the launch covers the chunks by0 .. by0 + n_first - 1 and, after them, by1 .. (a slab launches the chunks next to
+    // its two neighbours together)
+    const int bl = (int)(wg / (unsigned)tp.ntile);
+    const int bx = (int)(wg % (unsigned)tp.ntile), by = bl < n_first ? by0 + bl : by1 + (bl - n_first);
     const int ytile = trio_tile_start(tp, bx);
     const int yend = bx + 1 < tp.ntile ? trio_tile_start(tp, bx + 1) : ny;
     const int nv = (yend < ny ? yend : ny) - ytile;
@@ -2404,11 +2453,44 @@ static bool trio_ok(const cfd_handle* h) {
            h->variant < 0 && (!ghosts || (h->ghost_mask_depth >= 2 && p.nx >= 3));
 }
 
+#ifndef CFD_KERNEL_TEMPLATES_ONLY
+// The XCD the first workgroup of a launch on `stream` runs on (the queue constant o_q of xcd_fill_rank), measured
+// once per stream with a one-workgroup kernel that reads the hardware's XCC_ID register; -1 if it cannot be measured.
+__global__ void xcc_probe_kernel(int* out) {
+    if (threadIdx.x == 0) out[0] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15);      // XCC_ID: register 20, bits 3:0
+}
+static int xcc_offset_of(int device, hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int> known;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(device, stream);
+    auto it = known.find(key);
+    if (it != known.end()) return it->second;
+    int off = -1, *d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(int)) == hipSuccess) {
+        // three launches must agree: the constant belongs to the queue, not to the launch
+        int v[3] = {-1, -2, -3};
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) {
+            hipLaunchKernelGGL(xcc_probe_kernel, dim3(1), dim3(64), 0, stream, d);
+            ok = hipMemcpyAsync(&v[k], d, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                 hipStreamSynchronize(stream) == hipSuccess;
+        }
+        if (ok && v[0] == v[1] && v[1] == v[2] && v[0] >= 0 && v[0] < 8) off = v[0];
+        (void)hipFree(d);
+    }
+    known[key] = off;
+    return off;
+}
+#endif
+
 // src: the slot the step starts from; dst: the slot that receives the step's result; fpp / fprev (both or neither):
 // the filter's older time level and the buffer that receives the filtered values of EVERY owned cell.
 // c0, c1: the range of chunks (of h->trio_chunk planes) to launch; c1 < 0: all of them.
+// d0, d1: a second range of chunks in the same launch (empty by default).
+// busy: blocks of a launch of this step that is running beside this one (0: none): see xcd_fill_rank.
 static int launch_trio(cfd_handle* h, const double* src, double* dst, const double* fpp, double* fprev, int c0 = 0,
-                       int c1 = -1) {
+                       int c1 = -1, int d0 = 0, int d1 = 0, int busy = 0) {
     const cfd_params& p = h->p;
     EventPair ev{};
     if (h->timing) {
@@ -2426,7 +2508,21 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
     const TrioTiles tp = trio_tiles(p.ny, wmax, gran);
     const int nchunk = trio_nchunk(h);
     if (c1 < 0) c1 = nchunk;
-    if (c1 <= c0) return CFD_OK;        // empty range: nothing launched
+    if (c1 < c0) c1 = c0;
+    if (d1 < d0) d1 = d0;
+    const int nblk = (c1 - c0) + (d1 - d0);
+    if (nblk <= 0) return CFD_OK;       // empty ranges: nothing launched
+    // beside a running launch: one block per compute unit, eight XCDs of cus / 8 compute units
+    const int xcd_cap = h->cus_device / 8;
+    int grid = tp.ntile * nblk;
+    int xcd_off = 0;
+    if (busy > 0 && nts == 256 && h->cus == h->cus_device && h->cus_device % 8 == 0 && h->xcd_fill) {
+        const int oa = xcc_offset_of(h->device, h->interior_stream), ob = xcc_offset_of(h->device, h->stream);
+        const int g = oa < 0 || ob < 0 ? 0 : xcd_fill_grid(grid, busy, xcd_cap, oa, ob);
+        if (g > 0) { grid = g; xcd_off = oa | (ob << 4); } else busy = 0;
+    } else {
+        busy = 0;
+    }
     const size_t lds = (size_t)TRIO_LDS_ROWS * nts * sizeof(double);
     // with a neighbouring slab the stored values reach three ghost planes out
     const int lo0 = p.ghost_lo ? -3 : 0, hi0 = p.ghost_hi ? p.nx + 2 : p.nx - 1;
@@ -2438,8 +2534,9 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr_set[h->device & 63] = true;                                                       \
         }                                                                                          \
-        hipExtLaunchKernelGGL(kern, dim3(tp.ntile * (c1 - c0)), dim3(3 * NTS), lds, h->stream, ea, eb, 0, h->KF,    \
-                              src, dst, act, p.nx, p.ny, lo0, hi0, ch, h->trio_first, c0, wmax, gran, fpp, fprev); \
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(3 * NTS), lds, h->stream, ea, eb, 0, h->KF,             \
+                              src, dst, act, p.nx, p.ny, lo0, hi0, ch, h->trio_first, c0, c1 - c0, d0, wmax, gran, \
+                              busy, xcd_cap, xcd_off, fpp, fprev);                                 \
     } while (0)
     if (nts == 128) { if (fpp) LAUNCH_TRIO(128, 3, true); else LAUNCH_TRIO(128, 3, false); }
     else { if (fpp) LAUNCH_TRIO(256, 3, true); else LAUNCH_TRIO(256, 3, false); }
@@ -2453,12 +2550,12 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
 // writes slot t-1.  That slot is the buffer the step started from, which other blocks still read, so the filtered
 // values go to the scratch buffer, which then takes that slot's place (the step's source buffer becomes scratch).
 // c0, c1: chunk range as in launch_trio; finish: this call completes the step (slot rotation, time counters).
-static int step_trio(cfd_handle* h, int c0 = 0, int c1 = -1, bool finish = true) {
+static int step_trio(cfd_handle* h, int c0 = 0, int c1 = -1, bool finish = true, int d0 = 0, int d1 = 0, int busy = 0) {
     const int nc = (h->cmt + 1) % 3;
     const double* src = slot_base(h, h->cmt);
     const bool filter = h->cat + 1 > 1;
     int rc = launch_trio(h, src, slot_base(h, nc), filter ? slot_base(h, (h->cmt + 2) % 3) : nullptr,
-                         filter ? slot_base(h, 3) : nullptr, c0, c1);
+                         filter ? slot_base(h, 3) : nullptr, c0, c1, d0, d1, busy);
     if (rc || !finish) return rc;
     if (filter) {
         const int t = h->map[h->cmt];
@@ -2577,6 +2674,8 @@ static int create_impl(const cfd_params* p, const double* const fields[CFD_NPROP
     h->march3_ok = (double)NF3 * (double)h->plane * 8.0 < 4.0e9;
     h->cus = 256;
     if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->cus < 1) h->cus = 256;
+    h->cus_device = h->cus;
+    h->xcd_fill = !(getenv("CFD_TRIO_XCD_FILL") && atoi(getenv("CFD_TRIO_XCD_FILL")) == 0);
     // kernels with large LDS tiles run only where a workgroup may have that much (160 KiB on gfx950); elsewhere the
     // handle falls back to the forms that need little: the per-cell strict 3-D kernel, the two-sweeps 2-D kernel
     if (hipDeviceGetAttribute(&h->lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) != hipSuccess || h->lds_max < 1)
@@ -3040,6 +3139,7 @@ int cfd_step_one_pass_begin(cfd_handle* h) {
     HIP_TRY(hipSetDevice(h->device));
     auto& q = h->pend;
     trio_interior_chunks(h, &q.c0, &q.c1);
+    h->interior_stream = h->stream;
     int rc = step_trio(h, q.c0, q.c1, false);
     if (rc) return rc;
     q.trio = true;
@@ -3055,8 +3155,10 @@ int cfd_step_one_pass_end_on(cfd_handle* h, void* stream) {
     const int nchunk = trio_nchunk(h);
     const hipStream_t own = h->stream;
     h->stream = (hipStream_t)stream;
-    int rc = step_trio(h, 0, q.c0, false);
-    if (!rc) rc = step_trio(h, q.c1, nchunk, true);     // an empty range still completes the step
+    // the chunks next to the lower and to the upper neighbour in ONE launch: on one stream two launches would run one
+    // after the other (empty ranges still complete the step)
+    const int interior_blocks = (q.c1 - q.c0) * trio_tiles(h->p.ny, trio_wmax(h->trio_nts), trio_gran()).ntile;
+    int rc = step_trio(h, 0, q.c0, true, q.c1, nchunk, interior_blocks);
     h->stream = own;
     if (rc) return rc;
     q.open = false;
