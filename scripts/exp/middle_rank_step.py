@@ -15,14 +15,20 @@ from cfd_amd.solver import AdjGraph
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 delay_us = float(os.environ.get("DELAY_US", "0"))
-nx = ny = 4096
-params, fields, active = cases.synthetic_2d(nx, ny, seed=1)
-params = dict(params, dt=1e-7, flags=4)
+nz = int(os.environ.get("NZ", "1"))        # NZ > 1: an NZ^3 grid, three sweeps per step with a one-plane exchange each
+if nz > 1:
+    nx = ny = nz
+    params, fields, active = cases.synthetic_3d(nx, ny, nz, seed=3)
+else:
+    nx = ny = 4096
+    params, fields, active = cases.synthetic_2d(nx, ny, seed=1)
+params = dict(params, dt=1e-7, flags=int(os.environ.get("FLAGS", "4")))
 und = AdjGraph(params, fields, active)
 g = AdjGraph(dict(params, ghost_lo=1, ghost_hi=1), fields, active)
-act = np.ascontiguousarray(active, dtype=np.uint8).reshape(nx, ny)
-g.set_ghost_active(act[-2:], act[:2], depth=2)
-assert g.one_pass_step_available()
+if nz == 1:
+    act = np.ascontiguousarray(active, dtype=np.uint8).reshape(nx, ny)
+    g.set_ghost_active(act[-2:], act[:2], depth=2)
+    assert g.one_pass_step_available()
 main = torch.cuda.ExternalStream(g.stream())
 side = torch.cuda.Stream()
 
@@ -48,7 +54,31 @@ cycles = int(delay_us * float(os.environ.get("CYCLES_PER_US", "100")))     # tor
 _events = [torch.cuda.Event() for _ in range(64)]
 
 
+def slab_steps_3d(n):
+    k = 0
+    done = _events[k]; k = (k + 1) % 64
+    done.record(main)
+    for _ in range(n):
+        for sweep in range(3):
+            side.wait_event(done)
+            (slo, shi, rlo, rhi), nbytes = g.halo_planes(1)
+            with torch.cuda.stream(side):
+                if cycles:
+                    torch.cuda._sleep(cycles)
+                span(rlo, nbytes).copy_(span(shi, nbytes), non_blocking=True)
+                span(rhi, nbytes).copy_(span(slo, nbytes), non_blocking=True)
+            g.sweep_begin(sweep == 0, sweep == 2)
+            ev = _events[k]; k = (k + 1) % 64
+            ev.record(side)
+            main.wait_event(ev)
+            g.sweep_end()
+            done = _events[k]; k = (k + 1) % 64
+            done.record(main)
+
+
 def slab_steps(n):
+    if nz > 1:
+        return slab_steps_3d(n)
     k = 0
     done = _events[k]; k = (k + 1) % 64
     done.record(main)
@@ -89,7 +119,8 @@ if cycles:      # how long the sleep really is
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); torch.cuda._sleep(cycles); b.record(); torch.cuda.synchronize()
     print("delay kernel: %.1f us" % (a.elapsed_time(b) * 1e3))
-und.step(300); slab_steps(300); sync_all()       # warm up (clock settles under load)
+warm = 300 if nz == 1 else 20
+und.step(warm); slab_steps(warm); sync_all()       # warm up (clock settles under load)
 for r in range(3):
     print("undecomposed            %.4f ms/step (host issue %.4f)" % timed(lambda: und.step(steps), sync_all))
     print("slab, neighbours both sides (self-exchange%s)  %.4f ms/step (host issue %.4f)" % (
