@@ -82,6 +82,10 @@ struct cfd_multi {
     bool pair = false;          // the step's tail runs as one pass on every slab
     bool trio = false;          // the whole step runs as one pass on every slab (one three-plane exchange per step)
     bool overlap = true;
+    // Rehearsal on one GPU (cfd_multi_create_rank with world == 1 and env CFD_MULTI_LOOPBACK=1): the one slab is its own
+    // lower and upper neighbour, exchanging with itself through RCCL exactly as a middle rank exchanges with two others
+    // (a periodic domain: for timing the step of a rank, not for comparison with the reference).
+    bool loopback = false;
     size_t plane = 0;
     std::vector<Slab> slab;     // the slabs this process holds, in rank order
     std::vector<DeviceStreams> streams;
@@ -105,7 +109,7 @@ hipStream_t side_of(const cfd_multi* m, const Slab& s) { return m->streams[s.ds]
 enum Ready { READY_DONE, READY_EDGE };
 
 int exchange(cfd_multi* m, int depth, bool on_side, Ready ready) {
-    if (m->world == 1) return CFD_OK;
+    if (m->world == 1 && !m->loopback) return CFD_OK;
     struct Planes { void *slo, *shi, *rlo, *rhi; size_t bytes; };
     std::vector<Planes> pl(m->slab.size());
     for (size_t i = 0; i < m->slab.size(); ++i)
@@ -140,6 +144,13 @@ int exchange(cfd_multi* m, int depth, bool on_side, Ready ready) {
             const Slab& s = m->slab[i];
             hipStream_t st = on_side ? side_of(m, s) : main_of(m, s);
             const size_t count = pl[i].bytes / sizeof(double);
+            if (m->loopback) {      // sends and receives of one peer match in order: last planes -> lower ghosts, first -> upper
+                M_NCCL(ncclSend(pl[i].shi, count, ncclDouble, s.rank, s.comm, st));
+                M_NCCL(ncclRecv(pl[i].rlo, count, ncclDouble, s.rank, s.comm, st));
+                M_NCCL(ncclSend(pl[i].slo, count, ncclDouble, s.rank, s.comm, st));
+                M_NCCL(ncclRecv(pl[i].rhi, count, ncclDouble, s.rank, s.comm, st));
+                continue;
+            }
             if (s.rank > 0) {
                 M_NCCL(ncclSend(pl[i].slo, count, ncclDouble, s.rank - 1, s.comm, st));
                 M_NCCL(ncclRecv(pl[i].rlo, count, ncclDouble, s.rank - 1, s.comm, st));
@@ -202,7 +213,7 @@ int record(cfd_multi* m, bool edge_event) {
 // nodes of one snapshot, src/Main.hs:211); the planes next to a neighbour follow on the compute stream once the ghost
 // planes have arrived.  Otherwise everything is queued on the compute stream: exchange, interior, edge.
 int sweep_all(cfd_multi* m, int step_time, int with_filter) {
-    if (m->world == 1) {
+    if (m->world == 1 && !m->loopback) {
         for (Slab& s : m->slab) M_CFD(with_filter ? cfd_sweep_and_filter(s.h) : cfd_sweep(s.h, step_time));
         return record(m, false);
     }
@@ -228,7 +239,7 @@ int sweep_all(cfd_multi* m, int step_time, int with_filter) {
 }
 
 int step_once(cfd_multi* m) {
-    if (m->world == 1) {
+    if (m->world == 1 && !m->loopback) {
         for (Slab& s : m->slab) M_CFD(cfd_step(s.h, 1));
         M_CFD(record(m, false));
     } else if (m->trio && !m->overlap) {
@@ -314,8 +325,8 @@ int make_slab(cfd_multi* m, Slab& s, const double* const fields[CFD_NPROP], cons
     q.nx = s.x1 - s.x0;
     q.device = s.device;
     q.flags = m->p.flags | extra_flags;
-    q.ghost_lo = s.rank > 0;
-    q.ghost_hi = s.rank < m->world - 1;
+    q.ghost_lo = s.rank > 0 || m->loopback;
+    q.ghost_hi = s.rank < m->world - 1 || m->loopback;
     // Two slabs on one device run side by side, each on streams of its own and planning its launches for half the
     // compute units; more than two share one pair of streams (their launches then follow one another).
     M_CFD(streams_for(m, s.device, &s.ds, on_device == 2));
@@ -488,6 +499,7 @@ int cfd_multi_create_rank(const cfd_params* p, int rank, int world, const void* 
     m->transport = CFD_TRANSPORT_RCCL;
     m->plane = (size_t)p->ny * p->nz;
     m->overlap = env_flag("CFD_MULTI_OVERLAP", true);
+    m->loopback = world == 1 && env_flag("CFD_MULTI_LOOPBACK", false);
     m->slab.resize(1);
     Slab& s = m->slab[0];
     s.rank = rank;
@@ -508,6 +520,12 @@ int cfd_multi_create_rank(const cfd_params* p, int rank, int world, const void* 
         return code;
     };
     if (hipSetDevice(dev) != hipSuccess) return cleanup(fail(CFD_E_DEVICE, "cfd_multi_create_rank: hipSetDevice failed"));
+    if (m->loopback) {
+        ncclUniqueId id;
+        ncclResult_t r = ncclGetUniqueId(&id);
+        if (r == ncclSuccess) r = ncclCommInitRank(&s.comm, 1, id, 0);
+        if (r != ncclSuccess) return cleanup(fail(CFD_E_DEVICE, std::string("ncclCommInitRank (loopback): ") + ncclGetErrorString(r)));
+    }
     if (world > 1) {
         ncclUniqueId id;
         std::memcpy(&id, id128, sizeof id);
@@ -534,6 +552,16 @@ int cfd_multi_create_rank(const cfd_params* p, int rank, int world, const void* 
     const int extra = all[0] ? 0 : (p->nz == 1 ? CFD_FLAG_FORCE_3D : 0);
     const int depth = all[1] ? 2 : 1;
     if ((rc = make_slab(m, s, fields, active, extra)) != CFD_OK) return cleanup(rc);
+    if (m->loopback) {
+        // the slab is its own neighbour on both sides: its last planes' masks below, its first planes' above
+        if ((rc = cfd_set_ghost_active_depth(s.h, depth, active + (size_t)(p->nx - depth) * m->plane, active)) != CFD_OK)
+            return cleanup(rc);
+        int ok[2] = {0, 0};
+        if ((rc = cfd_pair_available(s.h, &ok[0])) != CFD_OK) return cleanup(rc);
+        if ((rc = cfd_one_pass_step_available(s.h, &ok[1])) != CFD_OK) return cleanup(rc);
+        m->pair = ok[0] && env_flag("CFD_MULTI_PAIR", true);
+        m->trio = ok[1] && m->pair && env_flag("CFD_MULTI_TRIO", true);
+    }
     if (world > 1) {
         // neighbours swap the masks of their first / last `depth` planes
         const size_t pb = (size_t)depth * m->plane;
@@ -665,7 +693,7 @@ int cfd_multi_info(cfd_multi* m, int* local_slabs, int* one_pass_tail, int* over
     if (!m) return fail(CFD_E_ARG, "cfd_multi_info: null handle");
     if (local_slabs) *local_slabs = (int)m->slab.size();
     if (one_pass_tail) *one_pass_tail = m->trio ? 2 : (m->pair ? 1 : 0);
-    if (overlapped) *overlapped = (m->overlap && m->world > 1) ? 1 : 0;
+    if (overlapped) *overlapped = (m->overlap && (m->world > 1 || m->loopback)) ? 1 : 0;
     return CFD_OK;
 }
 

@@ -338,7 +338,10 @@ int cfd_multi_create(const cfd_params *p, int n_slabs, const int32_t *devices, i
  * p->nx = its planes, p->device = its GPU, -1 = the current one).  The slabs talk through RCCL with a
  * communicator built from id128, the 128 bytes cfd_comm_unique_id wrote on ONE rank and the host sent to all
  * (any host-side channel: MPI, a file, torch.distributed).  Collective: every rank calls it, and afterwards
- * cfd_multi_step / cfd_multi_total_density, the same number of times. */
+ * cfd_multi_step / cfd_multi_total_density, the same number of times.
+ * Rehearsal on one GPU: with world == 1 and CFD_MULTI_LOOPBACK=1 in the environment the slab is its own lower and
+ * upper neighbour (a periodic domain) and exchanges its ghost planes with itself through RCCL every step, as a rank
+ * between two others does -- for timing and for testing the exchange, not for comparison with the reference. */
 #define CFD_COMM_ID_BYTES 128
 int cfd_comm_unique_id(void *id128);
 int cfd_multi_create_rank(const cfd_params *p, int rank, int world, const void *id128,

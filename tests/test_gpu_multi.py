@@ -263,3 +263,54 @@ def test_exchange_timing_counts_the_exchanges_of_a_step(flags, shape, n, per_ste
     assert m.exchange_timing() == (0.0, 0)
     g.step(6)
     _assert_same(m, g, "after timed steps")
+
+
+class _Span:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+@pytest.mark.parametrize("flags,shape", [(FAST, (40, 300, 1)), (FAST, (4, 33, 1)), (FAST, (2, 50, 1)), (0, (9, 40, 1)),
+                                         (0, (12, 9, 7)), (FAST, (11, 18, 19))])
+def test_rccl_loopback_rank_equals_a_slab_exchanged_by_hand(flags, shape, monkeypatch):
+    """The rank form of the slab driver with the slab as its own lower and upper neighbour (CFD_MULTI_LOOPBACK: grouped
+    ncclSend / ncclRecv to itself on the side stream, the calls a rank between two others makes, every step form)
+    against the same periodic slab stepped through the single-handle API with its ghost planes copied by hand before
+    every sweep: all three slots bit-identical after every step."""
+    import torch
+    from cfd_amd.multi import MultiGraph
+    from cfd_amd.solver import AdjGraph
+    nx, ny, nz = shape
+    params, fields, active = small_case(nx, ny, nz, 79)
+    params = dict(params, flags=flags, device=0)
+    monkeypatch.setenv("CFD_MULTI_LOOPBACK", "1")
+    m = MultiGraph.for_rank(params, fields, active, 0, 1, None)
+    monkeypatch.delenv("CFD_MULTI_LOOPBACK")
+    assert m.info()[2] is True
+    g = AdjGraph(dict(params, ghost_lo=1, ghost_hi=1), fields, active)
+    act = np.ascontiguousarray(active, dtype=np.uint8).reshape(nx, ny * nz)
+
+    def fill(depth):
+        g.sync()
+        (slo, shi, rlo, rhi), nbytes = g.halo_planes(depth)
+        t = lambda ptr: torch.as_tensor(_Span(ptr, nbytes), device="cuda")
+        t(rlo).copy_(t(shi))
+        t(rhi).copy_(t(slo))
+        torch.cuda.synchronize()
+
+    for step in range(3):
+        m.step(1)
+        for sweep in range(3):      # by hand: an exchange before every sweep, the filter with the last one
+            fill(1)
+            if sweep < 2:
+                g.sweep(sweep == 0)
+            else:
+                g.sweep_and_filter()
+        assert (m.currModTime, m.currAbsTime) == (g.currModTime, g.currAbsTime)
+        for rel in range(3):
+            fm, fg = m.read_fields(rel), g.read_fields(rel)
+            for k in range(7):
+                assert bits_equal(fm[k], fg[k]), (step, rel, PROPS[k], float(np.max(np.abs(fm[k] - fg[k]))))
+    ms, n = m.exchange_timing()
+    assert n == 0
