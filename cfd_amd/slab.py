@@ -56,7 +56,9 @@ class GpuBackend:
         self.graph = AdjGraph(params, fields, active)
         plane = params["ny"] * params["nz"]
         act = np.ascontiguousarray(active, dtype=np.uint8).reshape(-1)
-        self._first_mask, self._last_mask = act[:plane].copy(), act[-plane:].copy()
+        self._plane, self._nx = plane, params["nx"]
+        two = min(2, params["nx"]) * plane
+        self._first_masks, self._last_masks = act[:two].copy(), act[-two:].copy()      # up to two planes, ascending x
         # run on torch's current stream so that torch.distributed's stream ordering covers the kernels
         self.graph.set_stream(torch.cuda.current_stream().cuda_stream)
         self._cache = {}
@@ -75,15 +77,19 @@ class GpuBackend:
             out.append(t)
         return out
 
-    def boundary_active(self):
-        """This slab's masks of its first and last plane (host arrays)."""
-        return self._first_mask, self._last_mask
+    def planes(self):
+        return self._nx
 
-    def mask_tensor(self, plane=None):
-        """A device tensor for exchanging a mask plane: a copy of `plane`, or an empty one to receive into."""
+    def boundary_active(self, depth=1):
+        """This slab's masks of its first and last `depth` planes (host arrays, ascending x)."""
+        n = depth * self._plane
+        return self._first_masks[:n], self._last_masks[-n:]
+
+    def mask_tensor(self, plane=None, depth=1):
+        """A device tensor for exchanging mask planes: a copy of `plane`, or an empty one to receive `depth` planes into."""
         torch = self._torch
         if plane is None:
-            return torch.empty(self._first_mask.size, dtype=torch.uint8, device="cuda")
+            return torch.empty(depth * self._plane, dtype=torch.uint8, device="cuda")
         return torch.from_numpy(np.ascontiguousarray(plane)).cuda()
 
     def halo_commit(self, depth=1):
@@ -114,13 +120,14 @@ class DistComm:
             ops.append(dist.P2POp(dist.irecv, recv_hi, self.rank + 1))
         return ops
 
-    def exchange_masks(self, backend):
-        """The neighbours' masks of the planes next to this slab: (lo, hi) host arrays, None at a domain end."""
+    def exchange_masks(self, backend, depth=1):
+        """The neighbours' masks of the `depth` planes next to this slab: (lo, hi) host arrays, None at a domain end."""
         if self.world == 1:
             return None, None
-        first, last = backend.boundary_active()
-        recv_lo = backend.mask_tensor() if self.rank > 0 else None
-        recv_hi = backend.mask_tensor() if self.rank < self.world - 1 else None
+        first, last = backend.boundary_active(depth) if depth > 1 else backend.boundary_active()
+        empty = (lambda: backend.mask_tensor(None, depth)) if depth > 1 else backend.mask_tensor
+        recv_lo = empty() if self.rank > 0 else None
+        recv_hi = empty() if self.rank < self.world - 1 else None
         for req in self.dist.batch_isend_irecv(self._neighbour_ops(backend.mask_tensor(first), backend.mask_tensor(last),
                                                                    recv_lo, recv_hi)):
             req.wait()
@@ -130,6 +137,14 @@ class DistComm:
     def agree_pair(self, slab):
         slab.set_ghost_masks()
         return self.all_min(slab.backend, int(slab.backend.pair_available()))
+
+    def agree_one_pass(self, slab):
+        """Whether every rank can run a whole step as one pass behind ONE three-plane exchange: masks two planes deep
+        where every rank has two planes to show, then the smallest of the ranks' answers."""
+        if not self.all_min(slab.backend, int(slab.backend.planes() >= 2)):
+            return False
+        slab.set_ghost_masks(depth=2)
+        return bool(self.all_min(slab.backend, int(slab.backend.one_pass_step_available())))
 
     def all_min(self, backend, v):
         """Smallest of the ranks' integers."""
@@ -210,16 +225,24 @@ class LocalComm:
     def exchange_wait(self, backend, reqs, depth=1):
         self.exchange(backend, depth)
 
-    def exchange_masks(self, backend):
+    def exchange_masks(self, backend, depth=1):
         me = self.rank
-        lo = self.peers[me - 1].backend.boundary_active()[1] if me > 0 else None
-        hi = self.peers[me + 1].backend.boundary_active()[0] if me < len(self.peers) - 1 else None
+        get = (lambda b: b.boundary_active(depth)) if depth > 1 else (lambda b: b.boundary_active())
+        lo = get(self.peers[me - 1].backend)[1] if me > 0 else None
+        hi = get(self.peers[me + 1].backend)[0] if me < len(self.peers) - 1 else None
         return lo, hi
 
     def agree_pair(self, slab):
         for g in self.peers:
             g.set_ghost_masks()
         return all(g.backend.pair_available() for g in self.peers)
+
+    def agree_one_pass(self, slab):
+        if not all(hasattr(g.backend, "planes") and g.backend.planes() >= 2 for g in self.peers):
+            return False
+        for g in self.peers:
+            g.set_ghost_masks(depth=2)
+        return all(g.backend.one_pass_step_available() for g in self.peers)
 
     def all_sum(self, backend, v):
         """Sum over the virtual ranks, in rank order (every slab computes its own part: called on any of them,
@@ -256,16 +279,29 @@ class SlabGraph:
                 p["flags"] = int(p.get("flags", 0)) | 2         # CFD_FLAG_FORCE_3D: another slab has W != 0
         self.backend = backend_cls(p, fields, active)
         self.graph = self.backend.graph if hasattr(self.backend, "graph") else self.backend
-        self._masks_set = False
+        self._masks_set = 0         # depth of the neighbours' masks handed to the backend so far
         self._use_pair = None if pair else False
+        self._use_one_pass = None if pair else False
 
-    def set_ghost_masks(self):
-        """Hands the backend the neighbouring slabs' masks of the planes next to this slab (once; a
+    def set_ghost_masks(self, depth=1):
+        """Hands the backend the neighbouring slabs' masks of the `depth` planes next to this slab (once per depth; a
         collective with DistComm)."""
-        if not self._masks_set and self.world > 1:
-            lo, hi = self.comm.exchange_masks(self.backend)
-            self.backend.set_ghost_active(lo, hi)
-        self._masks_set = True
+        if self._masks_set < depth and self.world > 1:
+            if depth > 1:
+                lo, hi = self.comm.exchange_masks(self.backend, depth)
+                self.backend.set_ghost_active(lo, hi, depth)
+            else:
+                lo, hi = self.comm.exchange_masks(self.backend)
+                self.backend.set_ghost_active(lo, hi)
+        self._masks_set = max(self._masks_set, depth)
+
+    def use_one_pass(self):
+        """Whether a whole step (three sweeps and the filter) runs as one pass over memory behind ONE three-plane
+        exchange.  The ranks decide together, once (a collective with DistComm)."""
+        if self._use_one_pass is None:
+            self._use_one_pass = self.world > 1 and hasattr(self.backend, "one_pass_step_available") and \
+                hasattr(self.comm, "agree_one_pass") and bool(self.comm.agree_one_pass(self))
+        return self._use_one_pass
 
     def use_pair(self):
         """Whether the tail of a step (second and third sweep + filter) runs as one pass over memory with a
@@ -303,6 +339,11 @@ class SlabGraph:
     def step(self, nsteps=1):
         if self.world == 1 and hasattr(self.backend, "step"):
             self.backend.step(nsteps)       # undecomposed: the library's own step (second and third sweep in one pass)
+            return self
+        if self.use_one_pass():
+            for _ in range(nsteps):
+                self.comm.exchange(self.backend, depth=3)       # three planes per side: the whole step
+                self.backend.step_one_pass()
             return self
         pair = self.use_pair()
         for _ in range(nsteps):

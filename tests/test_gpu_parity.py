@@ -1068,6 +1068,54 @@ def test_full_size_slabs_equal_undecomposed(one_pass_tail):
                 assert bits_equal(got[k], want[k][r * half:(r + 1) * half]), (r, rel, PROPS[k])
 
 
+@pytest.mark.parametrize("shape,world,one_pass", [((15, 300, 1), 3, True), ((9, 33, 1), 3, True), ((5, 40, 1), 2, False),
+                                                  ((12, 9, 7), 2, False)])
+def test_torch_slab_driver_takes_the_one_pass_step(shape, world, one_pass):
+    """cfd_amd.slab.SlabGraph (the torch.distributed driver a multi-GPU bench falls back to), virtual ranks on this
+    GPU: where every slab has three planes and the grid is 2-D with re-associated arithmetic, its step is ONE
+    three-plane exchange and the one-pass step; otherwise the earlier forms.  Bit-identical to the undecomposed run."""
+    import torch
+    from cfd_amd.slab import LocalComm, SlabGraph, split_slabs
+    nx, ny, nz = shape
+    params, fields, active = small_case(nx, ny, nz, 83)
+    params = dict(params, flags=FAST)
+    ref = _gpu_graph(params, fields, active, FAST)
+    peers = []
+    for r, (x0, x1, f, a) in enumerate(split_slabs(fields, active, nx, ny * nz, world)):
+        peers.append(SlabGraph(dict(params, nx=x1 - x0), f, a, rank=r, world=world, comm=LocalComm(r, peers)))
+    assert [g.use_one_pass() for g in peers] == [one_pass] * world
+    for step in range(3):
+        ref.step(1)
+        if one_pass:
+            for g in peers:
+                g.comm.exchange(g.backend, depth=3)
+            torch.cuda.synchronize()
+            for g in peers:
+                g.backend.step_one_pass()
+        else:
+            for g in peers:
+                g.use_pair()
+            # virtual ranks step one after the other, which is only valid sweep by sweep: exchange all, then sweep all
+            for i, st in enumerate((True, False, False)):
+                for g in peers:
+                    g.exchange()
+                torch.cuda.synchronize()
+                for g in peers:
+                    if i == 2:
+                        g.backend.sweep_and_filter()
+                    else:
+                        g.backend.sweep(st)
+        torch.cuda.synchronize()
+        x = 0
+        for g in peers:
+            n = g.backend.planes() * ny * nz
+            for rel in range(3):
+                got, want = g.read_fields(rel), ref.read_fields(rel)
+                for k in range(7):
+                    assert bits_equal(got[k], want[k][x:x + n]), (step, rel, PROPS[k])
+            x += n
+
+
 @pytest.mark.timeout(400)
 @pytest.mark.parametrize("vary", [0, 2])
 def test_full_size_symmetry_3d(vary):
