@@ -2459,9 +2459,17 @@ static bool trio_ok(const cfd_handle* h) {
 __global__ void xcc_probe_kernel(int* out) {
     if (threadIdx.x == 0) out[0] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15);      // XCC_ID: register 20, bits 3:0
 }
+static std::mutex g_xcc_mu;
+static std::map<std::pair<int, hipStream_t>, int> g_xcc_known;
+// A stream that is destroyed takes its measurement with it (a later stream may get the same handle value and
+// another hardware queue).
+extern "C" void cfd_internal_forget_stream(int device, void* stream) {
+    std::lock_guard<std::mutex> lock(g_xcc_mu);
+    g_xcc_known.erase(std::make_pair(device, (hipStream_t)stream));
+}
 static int xcc_offset_of(int device, hipStream_t stream) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, int> known;
+    std::mutex& mu = g_xcc_mu;
+    std::map<std::pair<int, hipStream_t>, int>& known = g_xcc_known;
     std::lock_guard<std::mutex> lock(mu);
     const auto key = std::make_pair(device, stream);
     auto it = known.find(key);
@@ -2605,7 +2613,7 @@ void cfd_destroy(cfd_handle* h) {
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->d_active) (void)hipFree(h->d_active);
     if (h->d_partial) (void)hipFree(h->d_partial);
-    if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && h->own_stream) { cfd_internal_forget_stream(h->device, (void*)h->stream); (void)hipStreamDestroy(h->stream); }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
 }
@@ -3176,7 +3184,7 @@ int cfd_set_stream(cfd_handle* h, void* stream) {
     if (!h) return fail(CFD_E_ARG, "cfd_set_stream: null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->own_stream) HIP_TRY(hipStreamDestroy(h->stream));
+    if (h->own_stream) { cfd_internal_forget_stream(h->device, (void*)h->stream); HIP_TRY(hipStreamDestroy(h->stream)); }
     h->stream = (hipStream_t)stream;
     h->own_stream = false;
     return CFD_OK;

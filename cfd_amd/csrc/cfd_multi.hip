@@ -31,6 +31,7 @@
 
 extern "C" int cfd_internal_fail(int code, const char* msg);     // cfd_hip.hip: sets cfd_last_error's text
 // cfd_hip.hip: cfd_create on a stream the caller owns (the slab launches there from the start)
+extern "C" void cfd_internal_forget_stream(int device, void* stream);   // cfd_hip.hip: per-stream measurement dropped
 extern "C" int cfd_internal_set_cu_share(cfd_handle* h, int cus);   // cfd_hip.hip: plan launches for a share of the device
 extern "C" int cfd_internal_create_on(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
                                       void* stream, cfd_handle** out);
@@ -380,8 +381,8 @@ void cfd_multi_destroy(cfd_multi* m) {
         for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (DeviceStreams& d : m->streams) {
         (void)hipSetDevice(d.device);
-        if (d.side) (void)hipStreamDestroy(d.side);
-        if (d.main) (void)hipStreamDestroy(d.main);
+        if (d.side) { cfd_internal_forget_stream(d.device, (void*)d.side); (void)hipStreamDestroy(d.side); }
+        if (d.main) { cfd_internal_forget_stream(d.device, (void*)d.main); (void)hipStreamDestroy(d.main); }
     }
     delete m;
 }
