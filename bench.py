@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--virtual-slabs", type=int, default=1,
                     help="N = 1 only: cut this GPU's grid into K slabs driven by the library (copy transport), to "
                          "measure what the decomposition itself costs")
+    ap.add_argument("--loopback", action="store_true",
+                    help="N = 1 only, a rehearsal: this GPU's slab as a rank between two others -- it is its own lower and "
+                         "upper neighbour and exchanges its ghost planes with itself through the library's RCCL path "
+                         "every step (a periodic domain: the step is timed, the fields are not the reference's)")
     ap.add_argument("--no-preflight", action="store_true",
                     help="N > 1: skip the bit-for-bit check of the decomposition against an undecomposed run before timing")
     ap.add_argument("--preflight-timeout", type=float, default=420.0,
@@ -320,6 +324,11 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
     if a.dry_run:
         return dry_run(a, world, rank)
+    # Rank 0 prints ONE line on stdout.  Libraries write there too (RCCL prints a version banner when its first
+    # communicator is built): from here on file descriptor 1 is stderr, and the line goes to the saved stdout.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -327,7 +336,9 @@ def main():
     torch.cuda.set_device(local_rank)
     from cfd_amd import cases
     from cfd_amd.slab import SlabGraph, init_rccl
-    c_driver = a.slab_driver == "c" and (world > 1 or a.virtual_slabs > 1)
+    if a.loopback and (world > 1 or a.virtual_slabs > 1):
+        raise SystemExit("--loopback is a one-rank rehearsal")
+    c_driver = a.slab_driver == "c" and (world > 1 or a.virtual_slabs > 1 or a.loopback)
     watchdog = start_watchdog(a.preflight_timeout, "rendezvous + pre-flight", rank) if world > 1 else None
     if world > 1 and c_driver:
         import datetime
@@ -419,6 +430,10 @@ def main():
             def __init__(self):
                 if world > 1:
                     self.m = library_slab(params, fields, active)
+                elif a.loopback:
+                    os.environ["CFD_MULTI_LOOPBACK"] = "1"
+                    self.m = MultiGraph.for_rank(params, fields, active, 0, 1, None)
+                    del os.environ["CFD_MULTI_LOOPBACK"]
                 else:
                     self.m = MultiGraph(params, fields, active, a.virtual_slabs, devices=[local_rank] * a.virtual_slabs)
                 self.graph = self.m.slab(0)
@@ -486,9 +501,9 @@ def main():
         barrier()
     read_sclk = sclk_reader(local_rank)
     sclk = []
-    g.graph.set_timing(True)
+    g.graph.set_timing(os.environ.get("CFD_BENCH_KERNEL_TIMING", "1") != "0")
     g.graph.sweep_timing(reset=True)
-    timed_exchange = c_driver and hasattr(g, "m")
+    timed_exchange = c_driver and hasattr(g, "m") and os.environ.get("CFD_BENCH_EXCHANGE_TIMING", "1") != "0"
     if timed_exchange:
         g.m.exchange_timing(reset=True)
         g.m.set_exchange_timing(True)
@@ -590,14 +605,19 @@ def main():
         return rec
 
     kinds = []
-    if plain_sweeps:
+    untimed = not (launches or fused_launches or pair_launches or trio_launches)
+    if untimed:
+        # per-launch timing was off (a decomposed run: see where set_timing is called): the step at the wall clock
+        kinds.append(kind_record("whole step (%s)" % base_name, elapsed * 1e3, 0, a.steps, SWEEPS_PER_STEP, 1))
+        kinds[0]["timing"] = "wall clock per step (per-launch events off)"
+    elif plain_sweeps:
         kinds.append(kind_record(base_name, kernel_ms, launches, plain_sweeps, 1, 0))
-    if trio_launches:
+    if trio_launches and not untimed:
         kinds.append(kind_record("sweep2d_trio (three sweeps + filter in one pass)", trio_ms, trio_launches, a.steps, 3, 1,
                                  side_by_side=trio_launches > a.steps and a.virtual_slabs == 1))
-    if fused_launches:
+    if fused_launches and not untimed:
         kinds.append(kind_record(base_name + " + filter", fused_ms, fused_launches, a.steps, 1, 1))
-    if pair_launches:
+    if pair_launches and not untimed:
         kinds.append(kind_record("sweep2d_pair (two sweeps + filter in one pass)", pair_ms, pair_launches, a.steps, 2, 1))
     if a.virtual_slabs > 1:
         # several slabs on one GPU run side by side: per-launch durations overlap and say little; one record for the
@@ -637,7 +657,9 @@ def main():
                    "filter_passes_per_step": 1,
                    "decomposition": "x-slabs, %d rank(s)%s%s" % (
                        world, ", %d slabs on this GPU" % a.virtual_slabs if a.virtual_slabs > 1 else "",
-                       (", driven by the library (cfd_multi_*: %s)" % ("RCCL" if world > 1 else "device copies"))
+                       (", driven by the library (cfd_multi_*: %s)" % (
+                           "RCCL" if world > 1 else "RCCL loopback: the slab is its own neighbour on both sides, a "
+                           "periodic domain" if a.loopback else "device copies"))
                        if c_driver else (", driven by cfd_amd.slab over torch.distributed" if world > 1 else "")),
                    "kernel": kernel_name, "arithmetic": a.arith, "dt": a.dt,
                    "parity": "strict arithmetic: bit-exact against the CPU oracle (tests); fast (re-associated) arithmetic, "
@@ -673,7 +695,7 @@ def main():
     if rank == 0:
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
     if strict is None:
         g.close()
     if world > 1:
