@@ -432,6 +432,18 @@ def main():
                     self.m = library_slab(params, fields, active)
                 elif a.loopback:
                     os.environ["CFD_MULTI_LOOPBACK"] = "1"
+                    # what a pre-flight leaves behind in a rank's process: two rounds of an undecomposed graph and a
+                    # slab (communicator, streams) created, stepped and destroyed before the timed slab exists
+                    from cfd_amd.solver import AdjGraph
+                    for seed in (11, 12):
+                        sp, sf, sa = cases.synthetic_2d(48, 528, seed=seed) if two_d else cases.synthetic_3d(12, 20, 18, seed=seed)
+                        sp = dict(sp, dt=a.dt, flags=run_flags, device=local_rank)
+                        ref, sl = AdjGraph(sp, sf, sa), MultiGraph.for_rank(sp, sf, sa, 0, 1, None)
+                        ref.step(3)
+                        sl.step(3)
+                        sl.total_density()
+                        sl.close()
+                        ref.close()
                     self.m = MultiGraph.for_rank(params, fields, active, 0, 1, None)
                     del os.environ["CFD_MULTI_LOOPBACK"]
                 else:
