@@ -2463,6 +2463,13 @@ static std::mutex g_xcc_mu;
 static std::map<std::pair<int, hipStream_t>, int> g_xcc_known;
 // A stream that is destroyed takes its measurement with it (a later stream may get the same handle value and
 // another hardware queue).
+// For the tests: the placement of `units` blocks beside a launch of `busy` blocks (xcd_fill_grid / xcd_fill_rank);
+// rank_of[b] for b < the returned grid size (at most `max` entries written).
+extern "C" int cfd_internal_xcd_fill(int units, int busy, int cap, int oa, int ob, int* rank_of, int max) {
+    const int grid = xcd_fill_grid(units, busy, cap, oa, ob);
+    for (int b = 0; b < grid && b < max; ++b) rank_of[b] = xcd_fill_rank(b, busy, cap, oa, ob);
+    return grid;
+}
 extern "C" void cfd_internal_forget_stream(int device, void* stream) {
     std::lock_guard<std::mutex> lock(g_xcc_mu);
     g_xcc_known.erase(std::make_pair(device, (hipStream_t)stream));

@@ -77,3 +77,37 @@ def test_compiled_host_fails_loudly_without_gpu():
     out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=100)
     assert out.returncode != 0
     assert "cfd_create" in out.stderr
+
+
+def test_placement_of_blocks_beside_a_running_launch():
+    """The host arithmetic that places a slab's late blocks on the XCDs with compute units left (a pure function of the
+    library, no GPU): workgroup i of the running launch sits on XCD (i + oa) % 8, workgroup b of the late launch on
+    (b + ob) % 8; the blocks that take work are numbered 0 .. units-1 in launch order, no XCD gets more than it has
+    room for, and nothing is placed when the room does not suffice."""
+    import ctypes
+    import random
+    from cfd_amd import _capi
+    lib = _capi.load()
+    fill = lib.cfd_internal_xcd_fill
+    fill.restype = ctypes.c_int
+    fill.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    rng = random.Random(5)
+    out = (ctypes.c_int * 4096)()
+    cases = [(34, 221, 32, 7, 0), (17, 238, 32, 0, 3), (34, 221, 32, 0, 0)]
+    cases += [(rng.randint(1, 60), rng.randint(0, 256), 32, rng.randint(0, 7), rng.randint(0, 7)) for _ in range(300)]
+    for units, busy, cap, oa, ob in cases:
+        used = [sum(1 for i in range(busy) if (i + oa) % 8 == x) for x in range(8)]
+        free = [max(0, cap - u) for u in used]
+        grid = fill(units, busy, cap, oa, ob, out, 4096)
+        if sum(free) < units:
+            assert grid == 0
+            continue
+        assert 0 < grid <= 4096
+        ranks = [out[b] for b in range(grid)]
+        real = [r for r in ranks if r >= 0]
+        assert real == list(range(len(real))) and len(real) == units and ranks[-1] == units - 1
+        per_xcd = [0] * 8
+        for b, r in enumerate(ranks):
+            if r >= 0:
+                per_xcd[(b + ob) % 8] += 1
+        assert all(per_xcd[x] <= free[x] for x in range(8)), (units, busy, oa, ob, per_xcd, free)
