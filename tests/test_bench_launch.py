@@ -20,7 +20,11 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
+    if "--loopback" in extra:
+        assert r.stdout.strip() == lines[0], r.stdout        # nothing but the line
     rec = json.loads(lines[0])
+    if "--loopback" in extra:
+        assert rec["config"]["halo_exchange"]["per_step"] in (1.0, 3.0) and rec["config"]["halo_exchange"]["avg_ms"] > 0
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["value"] is None
 
 
@@ -39,10 +43,13 @@ import pytest
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [(), ("--virtual-slabs", "2"), ("--nz", "24", "--nx", "40", "--ny", "36")])
+@pytest.mark.parametrize("extra", [(), ("--virtual-slabs", "2"), ("--nz", "24", "--nx", "40", "--ny", "36"), ("--loopback",),
+                                   ("--loopback", "--nz", "24", "--nx", "40", "--ny", "36")])
 def test_bench_line_on_the_gpu(extra):
     """The command the round-end driver runs, shortened: ONE JSON line with the contract's keys, the roofline
-    and the finite-fields flag -- undecomposed, as two slabs behind the library's slab driver, and 3-D."""
+    and the finite-fields flag -- undecomposed, as two slabs behind the library's slab driver, 3-D, and as a rank
+    between two others (the slab exchanges with itself through the library's RCCL path: stdout must still hold the
+    one line although RCCL prints a banner, and the line reports the exchanges)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     args = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--warmup-seconds", "0", "--no-cpu-baseline"]
     if "--nz" not in extra:
@@ -52,7 +59,11 @@ def test_bench_line_on_the_gpu(extra):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
+    if "--loopback" in extra:
+        assert r.stdout.strip() == lines[0], r.stdout        # nothing but the line
     rec = json.loads(lines[0])
+    if "--loopback" in extra:
+        assert rec["config"]["halo_exchange"]["per_step"] in (1.0, 3.0) and rec["config"]["halo_exchange"]["avg_ms"] > 0
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in rec, key
