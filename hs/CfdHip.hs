@@ -77,6 +77,19 @@ foreign import ccall safe "cfd_multi_step" c_multiStep :: Ptr CfdMulti -> CInt -
 foreign import ccall safe "cfd_multi_total_density" c_multiDensity :: Ptr CfdMulti -> Ptr Double -> IO CInt
 foreign import ccall safe "cfd_multi_read_fields" c_multiRead :: Ptr CfdMulti -> CInt -> Ptr (Ptr Double) -> IO CInt
 foreign import ccall safe "cfd_multi_time" c_multiTime :: Ptr CfdMulti -> Ptr CInt -> Ptr CInt -> IO CInt
+-- checkpoint / restart of a decomposed run (the slots of all local slabs, then the counters)
+foreign import ccall safe "cfd_multi_write_fields" c_multiWrite :: Ptr CfdMulti -> CInt -> Ptr (Ptr Double) -> IO CInt
+foreign import ccall safe "cfd_multi_set_time" c_multiSetTime :: Ptr CfdMulti -> CInt -> CInt -> IO CInt
+-- one process per GPU: rank 0 makes the 128-byte communicator id, every rank creates its slab with it
+foreign import ccall safe "cfd_comm_unique_id" c_commUniqueId :: Ptr Word8 -> IO CInt
+foreign import ccall safe "cfd_multi_create_rank"
+    c_multiCreateRank :: Ptr Params -> CInt -> CInt -> Ptr Word8 -> Ptr (Ptr Double) -> Ptr Word8 -> Ptr (Ptr CfdMulti) -> IO CInt
+-- hosts that bring their own communication library and want the whole step as one pass on their slab: masks two
+-- planes deep once, then per step one three-plane exchange (cfd_halo_planes_depth with depth 3) and cfd_step_one_pass
+foreign import ccall safe "cfd_set_ghost_active_depth"
+    c_setGhostActiveDepth :: Ptr CfdHandle -> CInt -> Ptr Word8 -> Ptr Word8 -> IO CInt
+foreign import ccall safe "cfd_one_pass_step_available" c_onePassAvailable :: Ptr CfdHandle -> Ptr CInt -> IO CInt
+foreign import ccall safe "cfd_step_one_pass" c_stepOnePass :: Ptr CfdHandle -> IO CInt
 
 check :: String -> CInt -> IO ()
 check what rc = when (rc /= 0) $ do
