@@ -539,10 +539,17 @@ def main():
             # rank 0's figure: from the moment its stream gets to the exchange to the arrival of its ghost planes
             exchange = {"per_step": x_n / a.steps, "avg_ms": x_ms / x_n, "ms_per_step": x_ms / a.steps}
     base_name = g.graph.kernel_name()
+    rank_spread = None
     if world > 1:
+        own = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([own], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        # how far apart the ranks finished the timed steps (the value uses the slowest)
+        rank_spread = {"fastest_rank_ms_per_step": float(t.item()) / a.steps * 1e3,
+                       "slowest_rank_ms_per_step": elapsed / a.steps * 1e3}
 
     if c_driver and a.virtual_slabs > 1:
         # launches were timed on the first of the K slabs only: scale to the whole GPU
@@ -679,6 +686,7 @@ def main():
                              "sweep against strict; the strict kernels' rate is under \"strict\"",
                    "fast_vs_strict_one_step_on_this_workload": fast_vs_strict,
                    "halo_exchange": exchange,
+                   "ranks": rank_spread,
                    "preflight": preflight_report if world > 1 else "not applicable at N = 1 (no decomposition)",
                    "fields_finite_at_end": bool(final_density == final_density and abs(final_density) != float("inf"))},
         # the launch kind that takes most of the timed region; every kind is listed under "kernels"
