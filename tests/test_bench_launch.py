@@ -20,11 +20,7 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
-    if "--loopback" in extra:
-        assert r.stdout.strip() == lines[0], r.stdout        # nothing but the line
     rec = json.loads(lines[0])
-    if "--loopback" in extra:
-        assert rec["config"]["halo_exchange"]["per_step"] in (1.0, 3.0) and rec["config"]["halo_exchange"]["avg_ms"] > 0
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["value"] is None
 
 
