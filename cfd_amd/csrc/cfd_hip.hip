@@ -2531,7 +2531,8 @@ static int launch_trio(cfd_handle* h, const double* src, double* dst, const doub
     const int xcd_cap = h->cus_device / 8;
     int grid = tp.ntile * nblk;
     int xcd_off = 0;
-    if (busy > 0 && nts == 256 && h->cus == h->cus_device && h->cus_device % 8 == 0 && h->xcd_fill) {
+    // (eight XCDs: the whole device, not a partition of it)
+    if (busy > 0 && nts == 256 && h->cus == h->cus_device && h->cus_device % 8 == 0 && h->cus_device >= 128 && h->xcd_fill) {
         const int oa = xcc_offset_of(h->device, h->interior_stream), ob = xcc_offset_of(h->device, h->stream);
         const int g = oa < 0 || ob < 0 ? 0 : xcd_fill_grid(grid, busy, xcd_cap, oa, ob);
         if (g > 0) { grid = g; xcd_off = oa | (ob << 4); } else busy = 0;

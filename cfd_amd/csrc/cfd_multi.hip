@@ -308,7 +308,8 @@ bool env_flag(const char* name, bool dflt) {
 // A 300 us one-wave spin on a, a one-wave kernel on b: they overlap iff b's kernel is done while the spin still runs.
 __global__ void multi_spin_kernel(long long ticks) {
     const long long t0 = wall_clock64();        // 100 MHz
-    while (wall_clock64() - t0 < ticks) {}
+    // (bounded by a count of its own as well: it must end whatever the counter does)
+    for (int i = 0; i < 4000000 && wall_clock64() - t0 < ticks; ++i) {}
 }
 __global__ void multi_touch_kernel() {}
 
