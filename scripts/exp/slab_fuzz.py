@@ -1,4 +1,5 @@
-"""Random shapes, slab counts, arithmetic forms and chunk plans: a decomposed run (library slab driver, copy transport, all slabs\non this GPU) against the undecomposed one, three steps, all slots bit for bit.  usage: slab_fuzz.py [seed]"""
+"""Random shapes, slab counts, arithmetic forms and chunk plans: a decomposed run (library slab driver, copy transport, all slabs
+on this GPU) against the undecomposed one, three steps, all slots bit for bit.  usage: slab_fuzz.py [seed]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
