@@ -2149,6 +2149,8 @@ static void trio_plan(cfd_handle* h) {
     int margin = getenv("CFD_TRIO_EDGE_MARGIN") ? atoi(getenv("CFD_TRIO_EDGE_MARGIN")) : 32;
     if (margin > ch0 / 4) margin = ch0 / 4;
     if (!edges || nchunk < 3 || margin < 1) return;
+    // blocks that need more than one round of the device are not launched in two parts (cfd_internal_one_pass_blocks)
+    if ((long)nchunk * trio_tiles(p.ny, trio_wmax(h->trio_nts), trio_gran()).ntile > (long)(h->trio_nts == 128 ? 2 : 1) * h->cus) return;
     // edges * (ch - margin) + (nchunk - edges) * ch >= nx, with the last chunk (what is left) no longer than ch - margin
     // where it is next to a neighbour
     int ch = (p.nx + edges * margin + nchunk - 1) / nchunk;
@@ -2463,6 +2465,15 @@ static std::mutex g_xcc_mu;
 static std::map<std::pair<int, hipStream_t>, int> g_xcc_known;
 // A stream that is destroyed takes its measurement with it (a later stream may get the same handle value and
 // another hardware queue).
+// For cfd_multi.hip: blocks of the handle's one-pass step and the compute units it plans for.  A step whose blocks do
+// not fit the device at once is better not split into an interior and a late launch: the interior launch then holds
+// every compute unit for a whole block's time, and neither the exchange's kernel nor the late blocks can start.
+extern "C" int cfd_internal_one_pass_blocks(cfd_handle* h, int* blocks, int* cus) {
+    if (!h || !blocks || !cus) return fail(CFD_E_ARG, "cfd_internal_one_pass_blocks: null pointer");
+    *blocks = trio_nchunk(h) * trio_tiles(h->p.ny, trio_wmax(h->trio_nts), trio_gran()).ntile;
+    *cus = (h->trio_nts == 128 ? 2 : 1) * h->cus;
+    return CFD_OK;
+}
 // For the tests: the placement of `units` blocks beside a launch of `busy` blocks (xcd_fill_grid / xcd_fill_rank);
 // rank_of[b] for b < the returned grid size (at most `max` entries written).
 extern "C" int cfd_internal_xcd_fill(int units, int busy, int cap, int oa, int ob, int* rank_of, int max) {

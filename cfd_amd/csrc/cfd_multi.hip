@@ -31,6 +31,7 @@
 
 extern "C" int cfd_internal_fail(int code, const char* msg);     // cfd_hip.hip: sets cfd_last_error's text
 // cfd_hip.hip: cfd_create on a stream the caller owns (the slab launches there from the start)
+extern "C" int cfd_internal_one_pass_blocks(cfd_handle* h, int* blocks, int* cus);    // cfd_hip.hip
 extern "C" void cfd_internal_forget_stream(int device, void* stream);   // cfd_hip.hip: per-stream measurement dropped
 extern "C" int cfd_internal_set_cu_share(cfd_handle* h, int cus);   // cfd_hip.hip: plan launches for a share of the device
 extern "C" int cfd_internal_create_on(const cfd_params* p, const double* const fields[CFD_NPROP], const uint8_t* active,
@@ -88,6 +89,7 @@ struct cfd_multi {
     // lower and upper neighbour, exchanging with itself through RCCL exactly as a middle rank exchanges with two others
     // (a periodic domain: for timing the step of a rank, not for comparison with the reference).
     bool loopback = false;
+    int trio_one_round = -1;    // see trio_fits_one_round
     size_t plane = 0;
     std::vector<Slab> slab;     // the slabs this process holds, in rank order
     std::vector<DeviceStreams> streams;
@@ -240,11 +242,26 @@ int sweep_all(cfd_multi* m, int step_time, int with_filter) {
     return record(m, false);
 }
 
+// whether every local slab's one-pass step is a single round of blocks on its device (decided once)
+bool trio_fits_one_round(cfd_multi* m) {
+    if (m->trio_one_round < 0) {
+        m->trio_one_round = 1;
+        for (Slab& s : m->slab) {
+            int blocks = 0, cus = 0;
+            if (cfd_internal_one_pass_blocks(s.h, &blocks, &cus) != CFD_OK || blocks > cus) m->trio_one_round = 0;
+        }
+    }
+    return m->trio_one_round == 1;
+}
+
 int step_once(cfd_multi* m) {
     if (m->world == 1 && !m->loopback) {
         for (Slab& s : m->slab) M_CFD(cfd_step(s.h, 1));
         M_CFD(record(m, false));
-    } else if (m->trio && !m->overlap) {
+    } else if (m->trio && !(m->overlap && trio_fits_one_round(m))) {
+        // (also where a slab's blocks do not fit its device at once: beside an interior launch that holds every compute
+        // unit for a whole block's time neither the exchange's kernel nor the late blocks could start; measured on a
+        // 2048 x 16384 slab: 1.545 ms per step split against 1.425 undecomposed)
         M_CFD(exchange(m, 3, false, READY_DONE));
         for (Slab& s : m->slab) M_CFD(cfd_step_one_pass(s.h));
         M_CFD(record(m, false));
