@@ -228,12 +228,17 @@ int sweep_all(cfd_multi* m, int step_time, int with_filter) {
         }
         M_CFD(exchange(m, 1, true, READY_DONE));
         for (Slab& s : m->slab) M_CFD(cfd_sweep_begin_depth(s.h, step_time, with_filter, 1));
+        // the planes next to a neighbour: on the side stream right behind the exchange, beside the interior launch (a
+        // sweep fused with the filter completes on the compute stream only: there they follow the interior launch)
+        if (!with_filter)
+            for (Slab& s : m->slab) M_CFD(cfd_sweep_end_on(s.h, (void*)side_of(m, s)));
         for (Slab& s : m->slab) {
             M_HIP(hipSetDevice(s.device));
             M_HIP(hipEventRecord(s.side_done, side_of(m, s)));
             M_HIP(hipStreamWaitEvent(main_of(m, s), s.side_done, 0));
         }
-        for (Slab& s : m->slab) M_CFD(cfd_sweep_end(s.h));
+        if (with_filter)
+            for (Slab& s : m->slab) M_CFD(cfd_sweep_end(s.h));
         return record(m, false);
     }
     M_CFD(exchange(m, 1, false, READY_DONE));
